@@ -1,0 +1,172 @@
+/*
+ * rt_shim.h — C ABI of the MI355X trace path (librt_amd.so).
+ *
+ * The reference (zanders3/raytracer) has no plugin or FFI interface; its trace
+ * path is reached through plain C++ seams with global state.  Each entry point
+ * below replaces one of those seams, cited as Raytracer/<file>:<line>:
+ *
+ *   scene construction   main.cpp:240-255 (`scene.push_back(new Sphere/Plane…)`)
+ *   mesh flatten         main.cpp:219-232 (`LoadModel(const char*)` → `new Triangle`)
+ *   camera literals      main.cpp:267-270
+ *   per-pixel loop       main.cpp:262-277 (calls raytrace(), main.cpp:144-217, and
+ *                        quantises into `color image[]`, texturerenderer.h:14-16)
+ *
+ * Conventions: plain pointers and sizes only.  Every call returns 0 on success
+ * or a negative RT_E_* code; rt_last_error() gives the text for the calling
+ * thread.  The host owns host buffers, the library owns device buffers.  One
+ * host thread per context.  There is no CPU fallback: without a usable HIP
+ * device rt_create() fails.
+ */
+#ifndef RT_SHIM_H
+#define RT_SHIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_E_INVALID = -1,     /* bad argument */
+    RT_E_DEVICE = -2,      /* HIP runtime error */
+    RT_E_NOMEM = -3,       /* device or host allocation failed */
+    RT_E_STATE = -4,       /* call order (e.g. render before a scene is set) */
+    RT_E_LIMIT = -5        /* size beyond a stated maximum */
+};
+
+typedef struct rt_ctx rt_ctx;
+
+/* struct Material, main.cpp:29-36.  Reference defaults: 0, 1, 1, (1,1,1). */
+typedef struct {
+    float reflect, diffuse, spec;
+    float color[3];
+} rt_material;
+
+enum { RT_SPHERE = 0, RT_PLANE = 1 };
+
+/* One analytic entry of the reference's `scene` vector (main.cpp:137):
+ * struct Sphere main.cpp:48-74 (p = centre, s = radius) or
+ * struct Plane  main.cpp:76-98 (p = normal, s = offset).
+ * is_light is Primitive::isLight (main.cpp:42); only spheres may be lights because
+ * main.cpp:178 reads the light position through a Sphere*. */
+typedef struct {
+    int32_t kind;
+    int32_t is_light;
+    rt_material mat;
+    float p[3];
+    float s;
+} rt_analytic;
+
+/* The camera of main.cpp:267-270 with its literals as fields:
+ *   offsetX = x*pitch + off_x, offsetY = y*pitch + off_y,
+ *   direction = normalize((offsetX, offsetY, plane_z) - origin).
+ * Reference values: origin (0,0,-5), pitch 0.01f, off_x = off_y = -4.0f, plane_z 0. */
+typedef struct {
+    float origin[3];
+    float pitch, off_x, off_y, plane_z;
+} rt_camera;
+
+/* Which image rows a call renders, in bands (for tile partitioning across GPUs).
+ * Local row r maps to image row
+ *   y = (first_band + (r / band_rows) * band_stride) * band_rows + r % band_rows
+ * and n_rows local rows are rendered into a compact buffer (row r at r*W).
+ * A contiguous slab [y0,y1) is {first_band=y0, band_rows=1, band_stride=1, n_rows=y1-y0}. */
+typedef struct {
+    int32_t first_band, band_rows, band_stride, n_rows;
+} rt_rowset;
+
+/* Filled by rt_get_stats().  Ray counts follow the reference's own casting rules:
+ * one primary ray per pixel (main.cpp:270-272), one shadow ray per light per
+ * non-emissive hit (main.cpp:170-188), one reflection ray per hit with reflect > 0
+ * and depth < maxDepth (main.cpp:208-211). */
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_reflect;
+    uint64_t box_tests, tri_tests, analytic_tests;   /* only with RT_OPT_COUNT_TESTS = 1 */
+    float ms_frame;        /* device time of the last frame, first kernel to last kernel */
+    float ms_trace;        /* sum of the bounce (traversal + shading) kernels */
+    float ms_resolve;      /* recombination + quantise kernel */
+    int32_t n_launches;    /* kernels launched for the frame */
+    int32_t n_analytic, n_triangles;
+    int32_t bvh_nodes, bvh_depth, bvh_leaf_max;
+    int32_t accel;         /* 0 = linear scan over triangles, 1 = LBVH */
+    float ms_build;        /* device time of the last LBVH build */
+} rt_stats;
+
+enum {
+    RT_OPT_ACCEL = 1,        /* 0 auto (LBVH above RT_BRUTE_MAX triangles), 1 force linear scan, 2 force LBVH */
+    RT_OPT_COUNT_TESTS = 2,  /* 1: count box / triangle / analytic tests (slower kernels) */
+    RT_OPT_LEAF_MAX = 3,     /* triangles per LBVH leaf, 1..8 (takes effect at the next rt_set_*triangles) */
+    RT_OPT_TIMING = 4        /* 1 (default): record per-kernel device events for rt_get_stats */
+};
+
+#define RT_MAX_ANALYTIC 1024
+#define RT_MAX_DEPTH 64
+#define RT_BRUTE_MAX 48
+
+int rt_abi_version(void);
+const char *rt_last_error(void);
+
+/* Context on HIP device `device_ordinal`. */
+rt_ctx *rt_create(int device_ordinal);
+void rt_destroy(rt_ctx *ctx);
+
+int rt_set_option(rt_ctx *ctx, int option, int value);
+
+/* Replaces the `scene.push_back(new Sphere…/new Plane…)` block, main.cpp:240-255.
+ * Primitive ids 0..n-1 in array order (scene order decides ties, main.cpp:151). */
+int rt_set_analytic(rt_ctx *ctx, const rt_analytic *prims, int n);
+
+/* Replaces LoadModel(const char*), main.cpp:219-232: every index triple becomes a
+ * Triangle (constructor main.cpp:104-107 runs on the device), appended after the
+ * analytic primitives (ids n_analytic + k).  `mat` NULL = reference default material.
+ * Builds the LBVH on the device.  verts = n_verts x (x,y,z). */
+int rt_set_mesh(rt_ctx *ctx, const float *verts, int n_verts, const int32_t *indices, int n_indices,
+                const rt_material *mat);
+
+/* Same with the triangles already flattened: tri_verts = n_tris x (v1,v2,v3) x (x,y,z). */
+int rt_set_triangles(rt_ctx *ctx, const float *tri_verts, int n_tris, const rt_material *mat);
+
+/* Per-triangle materials (the reference gives every mesh triangle the default
+ * material, main.cpp:230 + 34; this is the data-driven generalisation):
+ * tri_material[k] indexes mats[]. */
+int rt_set_triangle_materials(rt_ctx *ctx, const rt_material *mats, int n_mats,
+                              const int32_t *tri_material, int n_tris);
+
+/* Replaces the literals of main.cpp:267-270.  NULL restores the reference camera. */
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+
+/* Replaces the pixel loop main.cpp:262-277 for rows [y0,y1) of a W x H frame with
+ * `max_depth` in place of the constant at main.cpp:18.  Synchronous; outputs are
+ * HOST buffers, any may be NULL:
+ *   rgb8    3*W*(y1-y0) bytes, pixel (x,y) at 3*((y-y0)*W+x), as `color image[]`
+ *   hit_id  W*(y1-y0) int32: index in scene order of the primary ray's nearest primitive, -1 = miss
+ *   rgb32   3*W*(y1-y0) floats: the colour before clamp/quantise */
+int rt_render_frame(rt_ctx *ctx, int W, int H, int y0, int y1, int max_depth,
+                    uint8_t *rgb8, int32_t *hit_id, float *rgb32);
+
+/* Same work with DEVICE output buffers and an explicit HIP stream (hipStream_t as
+ * void*, NULL = the context's own stream).  Asynchronous: returns after enqueueing.
+ * hit_t (optional) receives the primary ray's nearest t (FLT_MAX on a miss). */
+int rt_render_rows_device(rt_ctx *ctx, int W, int H, const rt_rowset *rows, int max_depth,
+                          void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, void *stream);
+
+/* Scatter a gathered set of compact band buffers back into a W x H image:
+ * src holds n_parts consecutive parts, part k rendered with
+ * {first_band=k, band_rows, band_stride=n_parts}, each padded to rows_per_part rows.
+ * bytes_per_pixel: 3 (rgb8), 4 (hit_id) or 12 (rgb32).  Device pointers, async on stream. */
+int rt_deinterleave_bands(rt_ctx *ctx, const void *d_src, void *d_dst, int W, int H, int band_rows,
+                          int n_parts, int rows_per_part, int bytes_per_pixel, void *stream);
+
+/* Waits for the context's outstanding work and reports counters/timings of the last frame. */
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* Wait for everything the context has enqueued. */
+int rt_synchronize(rt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

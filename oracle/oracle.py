@@ -52,6 +52,7 @@ def lib():
         L.rto_make_sphere.argtypes = [C.POINTER(Prim), f3, C.c_float]
         L.rto_make_plane.argtypes = [C.POINTER(Prim), f3, C.c_float]
         L.rto_make_triangle.argtypes = [C.POINTER(Prim), f3, f3, f3]
+        L.rto_make_mesh.argtypes = [C.POINTER(Prim), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Material), C.c_void_p]
         L.rto_default_camera.argtypes = [C.POINTER(Camera)]
         L.rto_scene_create.restype = C.c_void_p
         L.rto_scene_create.argtypes = [C.POINTER(Prim), C.c_int]
@@ -114,17 +115,31 @@ def camera(origin=(0.0, 0.0, -5.0), pitch=0.01, off_x=-4.0, off_y=-4.0, plane_z=
     return c
 
 
-def triangles_from_mesh(verts, indices, mat=None):
-    """The flatten of main.cpp:228-231: one Triangle per index triple."""
-    verts = np.asarray(verts, dtype=np.float32).reshape(-1, 3)
-    idx = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
-    return [triangle(verts[i0], verts[i1], verts[i2], mat) for i0, i1, i2 in idx]
+def triangles_from_mesh(verts, indices, mats=None, tri_mat=None):
+    """The flatten of main.cpp:228-231: one Triangle per index triple.  mats: list of
+    Material (tri_mat indexes it; None = mats[0] everywhere; mats None = default)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+    n = idx.size // 3
+    out = (Prim * max(n, 1))()
+    marr = (Material * len(mats))(*mats) if mats else None
+    tm = np.ascontiguousarray(tri_mat, dtype=np.int32) if tri_mat is not None else None
+    lib().rto_make_mesh(out, verts.ctypes.data, idx.ctypes.data, n, marr, tm.ctypes.data if tm is not None else None)
+    return out, n
 
 
 class Scene:
-    def __init__(self, prims, bvh=False):
-        self.n = len(prims)
-        arr = (Prim * max(self.n, 1))(*prims)
+    def __init__(self, prims, bvh=False, mesh=None):
+        """prims: list of Prim in scene order; mesh: optional (Prim array, count) from
+        triangles_from_mesh(), appended after them (as LoadModel does, main.cpp:257)."""
+        n0 = len(prims)
+        n1 = mesh[1] if mesh is not None else 0
+        self.n = n0 + n1
+        arr = (Prim * max(self.n, 1))()
+        for k, p in enumerate(prims):
+            arr[k] = p
+        if n1:
+            C.memmove(C.addressof(arr) + n0 * C.sizeof(Prim), mesh[0], n1 * C.sizeof(Prim))
         self._h = lib().rto_scene_create(arr, self.n)
         self.has_bvh = False
         if bvh:

@@ -76,6 +76,19 @@ void rto_make_triangle(rto_prim *p, const float v1[3], const float v2[3], const 
     p->n[0] = n.x;  p->n[1] = n.y;  p->n[2] = n.z;
 }
 
+/* The flatten of main.cpp:228-231 for a whole mesh: one Triangle per index triple.
+ * mats/tri_mat select a material per triangle (tri_mat NULL: mats[0] for all;
+ * mats NULL: reference default material). */
+void rto_make_mesh(rto_prim *out, const float *verts, const int *indices, int n_tris,
+                   const rto_material *mats, const int *tri_mat)
+{
+    for (int k = 0; k < n_tris; k++) {
+        rto_make_triangle(&out[k], verts + 3 * (size_t)indices[3 * k], verts + 3 * (size_t)indices[3 * k + 1],
+                          verts + 3 * (size_t)indices[3 * k + 2]);
+        if (mats) out[k].mat = mats[tri_mat ? tri_mat[k] : 0];
+    }
+}
+
 void rto_default_camera(rto_camera *c)                                                     /* main.cpp:267-269 */
 {
     c->origin[0] = 0.0f; c->origin[1] = 0.0f; c->origin[2] = -5.0f;

@@ -65,6 +65,8 @@ void rto_make_sphere(rto_prim *p, const float pos[3], float radius);          /*
 void rto_make_plane(rto_prim *p, const float normal[3], float offset);        /* main.cpp:81 */
 void rto_make_triangle(rto_prim *p, const float v1[3], const float v2[3],
                        const float v3[3]);                                    /* main.cpp:104-107 */
+void rto_make_mesh(rto_prim *out, const float *verts, const int *indices, int n_tris,
+                   const rto_material *mats, const int *tri_mat);             /* main.cpp:228-231 */
 void rto_default_camera(rto_camera *c);
 
 /* Opaque scene: primitives in scene order + optional CPU BVH over the triangles. */

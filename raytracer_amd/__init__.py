@@ -1,0 +1,248 @@
+"""raytracer_amd — MI355X-native trace path of zanders3/raytracer behind a C ABI.
+
+This package is a thin ctypes binding of librt_amd.so (include/rt_shim.h) plus a
+Python mirror of the reference's scene-building seam (Raytracer/main.cpp:240-257):
+the same primitive kinds, material fields and defaults, in the same scene order.
+There is no CPU fallback: if the HIP library is missing, or no HIP device is
+usable, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+RT_SPHERE, RT_PLANE = 0, 1
+OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING = 1, 2, 3, 4
+ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
+RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48
+
+# every symbol include/rt_shim.h declares
+ABI_SYMBOLS = (
+    "rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_option", "rt_set_analytic",
+    "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
+    "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize",
+)
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code
+
+
+class Material(C.Structure):
+    """struct Material, main.cpp:29-36 (defaults reflect 0, diffuse 1, spec 1, white)."""
+    _fields_ = [("reflect", C.c_float), ("diffuse", C.c_float), ("spec", C.c_float), ("color", C.c_float * 3)]
+
+    def __init__(self, reflect=0.0, diffuse=1.0, spec=1.0, color=(1.0, 1.0, 1.0)):
+        super().__init__()
+        self.reflect, self.diffuse, self.spec = reflect, diffuse, spec
+        self.color[:] = [float(c) for c in color]
+
+
+class Analytic(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("is_light", C.c_int32), ("mat", Material), ("p", C.c_float * 3), ("s", C.c_float)]
+
+
+class Camera(C.Structure):
+    """The literals of main.cpp:267-270."""
+    _fields_ = [("origin", C.c_float * 3), ("pitch", C.c_float), ("off_x", C.c_float), ("off_y", C.c_float),
+                ("plane_z", C.c_float)]
+
+    def __init__(self, origin=(0.0, 0.0, -5.0), pitch=0.01, off_x=-4.0, off_y=-4.0, plane_z=0.0):
+        super().__init__()
+        self.origin[:] = [float(c) for c in origin]
+        self.pitch, self.off_x, self.off_y, self.plane_z = pitch, off_x, off_y, plane_z
+
+
+class RowSet(C.Structure):
+    _fields_ = [("first_band", C.c_int32), ("band_rows", C.c_int32), ("band_stride", C.c_int32), ("n_rows", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("analytic_tests", C.c_uint64),
+                ("ms_frame", C.c_float), ("ms_trace", C.c_float), ("ms_resolve", C.c_float),
+                ("n_launches", C.c_int32), ("n_analytic", C.c_int32), ("n_triangles", C.c_int32),
+                ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("bvh_leaf_max", C.c_int32),
+                ("accel", C.c_int32), ("ms_build", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def Sphere(pos, radius, mat=None, is_light=False):
+    """struct Sphere, main.cpp:48-74."""
+    a = Analytic()
+    a.kind, a.is_light = RT_SPHERE, int(bool(is_light))
+    a.mat = mat if mat is not None else Material()
+    a.p[:] = [float(c) for c in pos]
+    a.s = radius
+    return a
+
+
+def Plane(normal, offset, mat=None):
+    """struct Plane, main.cpp:76-98."""
+    a = Analytic()
+    a.kind, a.is_light = RT_PLANE, 0
+    a.mat = mat if mat is not None else Material()
+    a.p[:] = [float(c) for c in normal]
+    a.s = offset
+    return a
+
+
+def stock_scene():
+    """The scene of main.cpp:240-255: mirror sphere, two light spheres, floor plane."""
+    return [
+        Sphere((0.0, 0.0, 0.0), 2.5, Material(reflect=1.0, diffuse=0.0)),
+        Sphere((2.0, 5.0, 1.0), 0.1, Material(color=(0.7, 0.7, 0.9)), is_light=True),
+        Sphere((-2.0, 5.0, -3.0), 0.1, Material(color=(0.9, 0.9, 0.4)), is_light=True),
+        Plane((0.0, 1.0, 0.0), -4.0),
+    ]
+
+
+def camera_for_width(W):
+    """Reference camera generalised to another width: the 0.01 pixel pitch of
+    main.cpp:268-269 is 8/800, so pitch = float32(8)/float32(W) spans the same
+    x range [-4, 4); at W = 800 it is bit-identical to the literal 0.01f."""
+    return Camera(pitch=float(np.float32(8.0) / np.float32(W)))
+
+
+_lib = None
+
+
+def load_library():
+    """Load librt_amd.so and declare its prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python raytracer_amd/build.py` "
+                           "(there is no CPU fallback for the trace path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.rt_abi_version.restype = i32
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_create.restype = vp
+    L.rt_create.argtypes = [i32]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_set_option.argtypes = [vp, i32, i32]
+    L.rt_set_analytic.argtypes = [vp, C.POINTER(Analytic), i32]
+    L.rt_set_mesh.argtypes = [vp, vp, i32, vp, i32, C.POINTER(Material)]
+    L.rt_set_triangles.argtypes = [vp, vp, i32, C.POINTER(Material)]
+    L.rt_set_triangle_materials.argtypes = [vp, C.POINTER(Material), i32, vp, i32]
+    L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.rt_render_frame.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.rt_render_rows_device.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
+    L.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_synchronize.argtypes = [vp]
+    _lib = L
+    return L
+
+
+class Context:
+    """One trace context on one GPU (rt_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self._h = self.L.rt_create(device)
+        if not self._h:
+            raise RtError(-2, self.L.rt_last_error().decode())
+        self.device = device
+        self.n_analytic = 0
+        self.n_tris = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.L.rt_last_error().decode())
+
+    def set_option(self, opt, value):
+        self._check(self.L.rt_set_option(self._h, opt, value))
+
+    def set_analytic(self, prims):
+        n = len(prims)
+        arr = (Analytic * max(n, 1))(*prims)
+        self._check(self.L.rt_set_analytic(self._h, arr, n))
+        self.n_analytic = n
+
+    def set_mesh(self, verts, indices, mat=None):
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        self._check(self.L.rt_set_mesh(self._h, v.ctypes.data, v.shape[0], i.ctypes.data, i.shape[0],
+                                       C.byref(mat) if mat is not None else None))
+        self.n_tris = i.shape[0] // 3
+
+    def set_triangles(self, tri_verts, mat=None):
+        t = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+        self._check(self.L.rt_set_triangles(self._h, t.ctypes.data, t.shape[0],
+                                            C.byref(mat) if mat is not None else None))
+        self.n_tris = t.shape[0]
+
+    def set_triangle_materials(self, mats, tri_material):
+        tm = np.ascontiguousarray(tri_material, dtype=np.int32).reshape(-1)
+        arr = (Material * len(mats))(*mats)
+        self._check(self.L.rt_set_triangle_materials(self._h, arr, len(mats), tm.ctypes.data, tm.shape[0]))
+
+    def set_camera(self, cam=None):
+        self._check(self.L.rt_set_camera(self._h, C.byref(cam) if cam is not None else None))
+
+    def render_frame(self, W, H, y0=0, y1=None, max_depth=3, want=("rgb8", "hit_id", "rgb32")):
+        """rt_render_frame: host numpy outputs for rows [y0, y1)."""
+        y1 = H if y1 is None else y1
+        rows = max(y1 - y0, 0)
+        rgb8 = np.zeros((rows, W, 3), np.uint8) if "rgb8" in want else None
+        hid = np.full((rows, W), -2, np.int32) if "hit_id" in want else None
+        rgb32 = np.zeros((rows, W, 3), np.float32) if "rgb32" in want else None
+        ptr = lambda a: a.ctypes.data if a is not None and a.size else None
+        self._check(self.L.rt_render_frame(self._h, W, H, y0, y1, max_depth, ptr(rgb8), ptr(hid), ptr(rgb32)))
+        return dict(rgb8=rgb8, hit_id=hid, rgb32=rgb32)
+
+    def render_rows_device(self, W, H, rowset, max_depth, d_rgb8=None, d_hit_id=None, d_rgb32=None, d_hit_t=None,
+                           stream=None):
+        """rt_render_rows_device: raw device pointers (ints), asynchronous on `stream`."""
+        self._check(self.L.rt_render_rows_device(self._h, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id, d_rgb32,
+                                                 d_hit_t, stream))
+
+    def deinterleave_bands(self, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part, bytes_per_pixel, stream=None):
+        self._check(self.L.rt_deinterleave_bands(self._h, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part,
+                                                 bytes_per_pixel, stream))
+
+    def synchronize(self):
+        self._check(self.L.rt_synchronize(self._h))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.L.rt_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+
+def band_rowset(H, band_rows, part, n_parts):
+    """Rows of part `part` when the image is dealt out in `band_rows`-row bands round-robin."""
+    n_bands = (H + band_rows - 1) // band_rows
+    mine = range(part, n_bands, n_parts)
+    n_rows = sum(min(band_rows, H - b * band_rows) for b in mine)
+    return RowSet(part, band_rows, n_parts, n_rows)
+
+
+def rows_per_part(H, band_rows, n_parts):
+    """Row capacity every part's buffer needs so that all parts gather at equal size."""
+    n_bands = (H + band_rows - 1) // band_rows
+    return ((n_bands + n_parts - 1) // n_parts) * band_rows

@@ -1,0 +1,484 @@
+// lbvh.hip — on-device triangle set-up and LBVH construction for gfx950.
+//
+// The reference has no acceleration structure: raytrace() scans every primitive
+// (Raytracer/main.cpp:149-156, 181-188).  The LBVH built here only PRUNES that
+// scan.  Every triangle a ray reaches still goes through the reference's
+// Möller–Trumbore arithmetic (main.cpp:109-129) on the same v1/e1/e2 values the
+// reference's constructor computes (main.cpp:104-107), so hit ids and distances
+// stay bit-equal as long as no padded box culls a triangle the test would accept.
+//
+// Pipeline (all kernels, no host geometry work):
+//   k_tri_setup_*   Triangle constructor: v1, e1, e2, N
+//   k_bounds        scene bounds of the triangle centroids (wave + block reduce, ordered-int atomics)
+//   k_morton        63-bit Morton code per centroid
+//   radix sort      8 passes x 8 bits, stable; one wave per 1024-key tile, ballot-based ranking
+//   k_karras        Karras 2012 hierarchy from the sorted codes
+//   k_node_depth    depth of every internal node (parent walk)
+//   k_refit_level   bottom-up box union, one launch per depth (no in-kernel hand-offs)
+//   k_emit          64-byte traversal nodes with both children's padded boxes; subtrees
+//                   of <= leaf_max triangles collapse into one leaf
+#include "rt_internal.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int SORT_TILE = 1024;   // keys per wave-sized block in the radix sort
+
+__device__ inline unsigned int float_to_ordered(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float ordered_to_float(unsigned int u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// ------------------------------------------------------------------ Triangle constructor (main.cpp:104-107)
+__device__ inline void tri_ctor(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy,
+                                float cz, int i, int mat_index, float4 *tri_mt, float4 *tri_n)
+{
+    // e1 = v2 - v1, e2 = v3 - v1                                   (maths.h:132)
+    float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    // N = e1.cross(e2).normalize()                                 (maths.h:165-172, 158-162)
+    float nx = e1y * e2z - e1z * e2y;
+    float ny = e1z * e2x - e1x * e2z;
+    float nz = e1x * e2y - e1y * e2x;
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    tri_mt[3 * (size_t)i + 0] = make_float4(ax, ay, az, 0.f);
+    tri_mt[3 * (size_t)i + 1] = make_float4(e1x, e1y, e1z, 0.f);
+    tri_mt[3 * (size_t)i + 2] = make_float4(e2x, e2y, e2z, 0.f);
+    tri_n[i] = make_float4(nx / len, ny / len, nz / len, __int_as_float(mat_index));
+}
+
+__global__ void k_tri_setup_flat(const float *__restrict__ v, int n, float4 *tri_mt, float4 *tri_n, int mat_index)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = v + 9 * (size_t)i;
+    tri_ctor(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], i, mat_index, tri_mt, tri_n);
+}
+
+// main.cpp:228-231: new Triangle(verts[inds[i]], verts[inds[i+1]], verts[inds[i+2]])
+__global__ void k_tri_setup_indexed(const float *__restrict__ verts, int n_verts, const int32_t *__restrict__ idx,
+                                    int n, float4 *tri_mt, float4 *tri_n, int mat_index, int *bad)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int i0 = idx[3 * (size_t)i], i1 = idx[3 * (size_t)i + 1], i2 = idx[3 * (size_t)i + 2];
+    if ((unsigned)i0 >= (unsigned)n_verts || (unsigned)i1 >= (unsigned)n_verts || (unsigned)i2 >= (unsigned)n_verts) {
+        *bad = 1;   // the reference would read out of bounds here; reported as RT_E_INVALID
+        i0 = i1 = i2 = 0;
+    }
+    const float *a = verts + 3 * (size_t)i0, *b = verts + 3 * (size_t)i1, *c = verts + 3 * (size_t)i2;
+    tri_ctor(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], i, mat_index, tri_mt, tri_n);
+}
+
+// ------------------------------------------------------------------ bounds + Morton codes
+// The box of a triangle is the box of the three points the intersector actually
+// sees: v1, v1+e1, v1+e2.
+__device__ inline void tri_box(const float4 *__restrict__ tri_mt, int i, float lo[3], float hi[3])
+{
+    float4 a = tri_mt[3 * (size_t)i], e1 = tri_mt[3 * (size_t)i + 1], e2 = tri_mt[3 * (size_t)i + 2];
+    float p[3] = { a.x, a.y, a.z }, q[3] = { a.x + e1.x, a.y + e1.y, a.z + e1.z },
+          r[3] = { a.x + e2.x, a.y + e2.y, a.z + e2.z };
+    for (int k = 0; k < 3; k++) {
+        lo[k] = fminf(p[k], fminf(q[k], r[k]));
+        hi[k] = fmaxf(p[k], fmaxf(q[k], r[k]));
+    }
+}
+
+__global__ void k_bounds(const float4 *__restrict__ tri_mt, int n, unsigned int *bounds /*[6] ordered: lo xyz, hi xyz*/)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    if (i < n) tri_box(tri_mt, i, lo, hi);
+    for (int k = 0; k < 3; k++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&bounds[k], float_to_ordered(lo[k]));
+            atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
+        }
+    }
+}
+
+__device__ inline unsigned long long expand21(unsigned long long v)
+{
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ void k_morton(const float4 *__restrict__ tri_mt, int n, const unsigned int *__restrict__ bounds,
+                         unsigned long long *keys, unsigned int *vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], hi[3];
+    tri_box(tri_mt, i, lo, hi);
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; k++) {
+        float slo = ordered_to_float(bounds[k]), shi = ordered_to_float(bounds[3 + k]);
+        float ext = shi - slo;
+        float c = 0.5f * (lo[k] + hi[k]);
+        float u = ext > 0.f ? (c - slo) / ext : 0.f;
+        float q = fminf(fmaxf(u * 2097152.0f, 0.f), 2097151.0f);
+        code |= expand21((unsigned long long)q) << (2 - k);
+    }
+    keys[i] = code;
+    vals[i] = (unsigned)i;
+}
+
+// ------------------------------------------------------------------ radix sort (LSD, 8 bits per pass, stable)
+// One 64-lane block per tile of SORT_TILE keys.  hist layout: [digit][tile] so an
+// exclusive scan of the flat array yields global scatter bases.
+__global__ __launch_bounds__(64) void k_sort_hist(const unsigned long long *__restrict__ keys, int n, int shift,
+                                                  unsigned int *hist, int n_tiles)
+{
+    __shared__ unsigned int h[256];
+    int lane = threadIdx.x, tile = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    __syncthreads();
+    int base = tile * SORT_TILE;
+    for (int r = 0; r < SORT_TILE / 64; r++) {
+        int i = base + r * 64 + lane;
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = lane; d < 256; d += 64) hist[(size_t)d * n_tiles + tile] = h[d];
+}
+
+// Exclusive scan of `m` counters by a single 1024-thread block (m is at most a few hundred thousand).
+__global__ __launch_bounds__(1024) void k_scan_exclusive(unsigned int *data, int m)
+{
+    __shared__ unsigned int wave_sum[16];
+    __shared__ unsigned int carry_s;
+    int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += 1024 * 4) {
+        int i0 = base + tid * 4;
+        unsigned int v[4], s = 0;
+        for (int k = 0; k < 4; k++) { v[k] = (i0 + k < m) ? data[i0 + k] : 0u; s += v[k]; }
+        unsigned int incl = s;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_sum[w] = incl;
+        __syncthreads();
+        unsigned int wprefix = 0;
+        for (int k = 0; k < w; k++) wprefix += wave_sum[k];
+        unsigned int carry = carry_s;
+        unsigned int excl = carry + wprefix + incl - s;
+        for (int k = 0; k < 4; k++) { if (i0 + k < m) data[i0 + k] = excl; excl += v[k]; }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wprefix + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sort_scatter(const unsigned long long *__restrict__ keys_in,
+                                                     const unsigned int *__restrict__ vals_in, int n, int shift,
+                                                     const unsigned int *__restrict__ hist_scanned, int n_tiles,
+                                                     unsigned long long *keys_out, unsigned int *vals_out)
+{
+    __shared__ unsigned int running[256];
+    int lane = threadIdx.x, tile = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) running[d] = hist_scanned[(size_t)d * n_tiles + tile];
+    __syncthreads();
+    int base = tile * SORT_TILE;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int r = 0; r < SORT_TILE / 64; r++) {
+        int i = base + r * 64 + lane;
+        bool valid = i < n;
+        unsigned long long key = valid ? keys_in[i] : ~0ull;
+        unsigned int digit = (unsigned)(key >> shift) & 255u;
+        // lanes holding the same digit (stable rank = position among them)
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < 8; b++) {
+            unsigned long long m = __ballot((digit >> b) & 1u);
+            peers &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        unsigned int rank = __popcll(peers & lt_mask);
+        unsigned int start = 0;
+        int leader = __ffsll((long long)peers) - 1;
+        if (valid && rank == 0) {
+            start = running[digit];
+            running[digit] = start + (unsigned)__popcll(peers);
+        }
+        start = __shfl(start, leader < 0 ? 0 : leader);
+        if (valid) {
+            unsigned int dst = start + rank;
+            keys_out[dst] = key;
+            vals_out[dst] = vals_in[i];
+        }
+        __syncthreads();   // one wave per block: orders the LDS updates of consecutive rounds
+    }
+}
+
+// ------------------------------------------------------------------ Karras 2012
+__device__ inline int delta(const unsigned long long *__restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+// Node ids: internal 0..n-2, leaf k = (n-1)+k.
+__global__ void k_karras(const unsigned long long *__restrict__ keys, int n, int2 *children, int2 *range, int *parent)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + (d < 0 ? d : 0);
+    int first = i < j ? i : j, last = i < j ? j : i;
+    int left = (first == gamma) ? (n - 1) + gamma : gamma;
+    int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+    children[i] = make_int2(left, right);
+    range[i] = make_int2(first, last);
+    parent[left] = i;
+    parent[right] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+__global__ void k_node_depth(const int *__restrict__ parent, int n_internal, int *depth, int *max_depth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    int d = 0;
+    for (int p = parent[i]; p >= 0; p = parent[p]) d++;
+    depth[i] = d;
+    atomicMax(max_depth, d);
+}
+
+// Leaf boxes: the intersector's triangle, padded so that rounding in the
+// Möller–Trumbore test (which can accept a ray passing slightly outside the exact
+// triangle) never lets the slab test cull a triangle the reference would hit.
+__global__ void k_leaf_boxes(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals, int n,
+                             const unsigned int *__restrict__ bounds, float4 *box_lo, float4 *box_hi)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float lo[3], hi[3];
+    tri_box(tri_mt, (int)sorted_vals[k], lo, hi);
+    float scene_abs = 0.f;
+    for (int a = 0; a < 3; a++)
+        scene_abs = fmaxf(scene_abs, fmaxf(fabsf(ordered_to_float(bounds[a])), fabsf(ordered_to_float(bounds[3 + a]))));
+    for (int a = 0; a < 3; a++) {
+        float pad = 2e-5f * scene_abs + 1e-4f * (hi[a] - lo[a]) + 1e-6f;
+        lo[a] -= pad;
+        hi[a] += pad;
+    }
+    box_lo[(n - 1) + k] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    box_hi[(n - 1) + k] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
+__global__ void k_refit_level(const int2 *__restrict__ children, const int *__restrict__ depth, int n_internal, int level,
+                              float4 *box_lo, float4 *box_hi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal || depth[i] != level) return;
+    int2 c = children[i];
+    float4 a = box_lo[c.x], b = box_lo[c.y], p = box_hi[c.x], q = box_hi[c.y];
+    box_lo[i] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
+    box_hi[i] = make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), 0.f);
+}
+
+// Traversal nodes.  A child whose sorted range holds <= leaf_max triangles becomes
+// a leaf reference ~(first*8 + count-1); nodes inside such a subtree are never
+// reached and are left zeroed.
+__global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
+                       const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
+                       const float4 *__restrict__ box_hi, BvhNode *nodes, int *live_depth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (parent[i] >= 0) {
+        // A non-root node spanning <= leaf_max triangles is referenced as a leaf by its
+        // parent, or lies inside such a leaf: never traversed.  Ranges nest, so every
+        // node spanning more than leaf_max triangles has only live ancestors.
+        int2 r = range[i];
+        if (r.y - r.x + 1 <= leaf_max) return;
+    }
+    int2 c = children[i];
+    int enc[2];
+    int cc[2] = { c.x, c.y };
+    for (int k = 0; k < 2; k++) {
+        if (cc[k] >= n - 1) {
+            enc[k] = ~(((cc[k] - (n - 1)) << 3) | 0);
+        } else {
+            int2 r = range[cc[k]];
+            int cnt = r.y - r.x + 1;
+            enc[k] = (cnt <= leaf_max) ? ~((r.x << 3) | (cnt - 1)) : cc[k];
+        }
+    }
+    float4 l0 = box_lo[c.x], h0 = box_hi[c.x], l1 = box_lo[c.y], h1 = box_hi[c.y];
+    BvhNode nd;
+    nd.xy0 = make_float4(l0.x, h0.x, l0.y, h0.y);
+    nd.xy1 = make_float4(l1.x, h1.x, l1.y, h1.y);
+    nd.z01 = make_float4(l0.z, h0.z, l1.z, h1.z);
+    nd.ch = make_int4(enc[0], enc[1], 0, 0);
+    nodes[i] = nd;
+    atomicMax(live_depth, depth[i] + 1);
+}
+
+__global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals, int n,
+                              float4 *bvh_tri)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    unsigned int src = sorted_vals[k];
+    float4 a = tri_mt[3 * (size_t)src], e1 = tri_mt[3 * (size_t)src + 1], e2 = tri_mt[3 * (size_t)src + 2];
+    a.w = __int_as_float((int)src);
+    bvh_tri[3 * (size_t)k] = a;
+    bvh_tri[3 * (size_t)k + 1] = e1;
+    bvh_tri[3 * (size_t)k + 2] = e2;
+}
+
+__global__ void k_init_bounds(unsigned int *bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
+};
+
+inline int blocks_for(int n, int bs) { return (n + bs - 1) / bs; }
+
+}  // namespace
+
+int tri_setup_flat(const float *d_tri_verts, int n_tris, float4 *tri_mt, float4 *tri_n, int mat_index, hipStream_t stream)
+{
+    if (n_tris <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_tri_setup_flat, dim3(blocks_for(n_tris, 256)), dim3(256), 0, stream, d_tri_verts, n_tris, tri_mt,
+                       tri_n, mat_index);
+    return hipGetLastError() == hipSuccess ? RT_OK : RT_E_DEVICE;
+}
+
+int tri_setup_indexed(const float *d_verts, int n_verts, const int32_t *d_indices, int n_tris, float4 *tri_mt,
+                      float4 *tri_n, int mat_index, int *d_bad_index_flag, hipStream_t stream)
+{
+    if (n_tris <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_tri_setup_indexed, dim3(blocks_for(n_tris, 256)), dim3(256), 0, stream, d_verts, n_verts,
+                       d_indices, n_tris, tri_mt, tri_n, mat_index, d_bad_index_flag);
+    return hipGetLastError() == hipSuccess ? RT_OK : RT_E_DEVICE;
+}
+
+void lbvh_free(LbvhResult *r)
+{
+    if (r->nodes) (void)hipFree(r->nodes);
+    if (r->bvh_tri) (void)hipFree(r->bvh_tri);
+    *r = LbvhResult();
+}
+
+int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, LbvhResult *out, std::string *err)
+{
+    lbvh_free(out);
+    if (n < 2) {
+        if (err) *err = "lbvh_build needs at least 2 triangles";
+        return RT_E_INVALID;
+    }
+    if (leaf_max < 1 || leaf_max > 8) {
+        if (err) *err = "leaf_max must be 1..8";
+        return RT_E_INVALID;
+    }
+    if ((long long)n * 8 >= (1ll << 31)) {
+        if (err) *err = "triangle count beyond the leaf encoding (2^28)";
+        return RT_E_LIMIT;
+    }
+    const int n_tiles = blocks_for(n, SORT_TILE);
+    DevBuf<unsigned int> bounds, vals[2], hist;
+    DevBuf<unsigned long long> keys[2];
+    DevBuf<int2> children, range;
+    DevBuf<int> parent, depth, scalars;
+    DevBuf<float4> box_lo, box_hi;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(bounds.alloc(6)); A(vals[0].alloc(n)); A(vals[1].alloc(n)); A(keys[0].alloc(n)); A(keys[1].alloc(n));
+    A(hist.alloc((size_t)256 * n_tiles)); A(children.alloc(n)); A(range.alloc(n)); A(parent.alloc(2 * (size_t)n));
+    A(depth.alloc(n)); A(scalars.alloc(2)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
+    A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
+    A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
+    if (e != hipSuccess) {
+        if (err) *err = std::string("lbvh_build allocation: ") + hipGetErrorString(e);
+        lbvh_free(out);
+        return RT_E_NOMEM;
+    }
+    hipEvent_t ev0, ev1;
+    RT_HIP_CHECK(hipEventCreate(&ev0), err);
+    RT_HIP_CHECK(hipEventCreate(&ev1), err);
+    RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
+
+    const int B = 256, G = blocks_for(n, B);
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds.p);
+    hipLaunchKernelGGL(k_bounds, dim3(G), dim3(B), 0, stream, tri_mt, n, bounds.p);
+    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, tri_mt, n, bounds.p, keys[0].p, vals[0].p);
+    int cur = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = pass * 8;
+        hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, n, shift, hist.p, n_tiles);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, hist.p, 256 * n_tiles);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, vals[cur].p, n, shift, hist.p,
+                           n_tiles, keys[cur ^ 1].p, vals[cur ^ 1].p);
+        cur ^= 1;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 2 * sizeof(int), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
+    hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
+                       parent.p);
+    hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
+    int max_depth = 0;
+    RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+    RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+    for (int level = max_depth; level >= 0; level--)
+        hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n - 1, level,
+                           box_lo.p, box_hi.p);
+    hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
+                       leaf_max, box_lo.p, box_hi.p, out->nodes, scalars.p + 1);
+    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, out->bvh_tri);
+    RT_HIP_CHECK(hipGetLastError(), err);
+    RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
+    int live_depth = 0;
+    RT_HIP_CHECK(hipMemcpyAsync(&live_depth, scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+    RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    out->n_nodes = n - 1;
+    out->depth = live_depth;
+    out->leaf_max = leaf_max;
+    out->ms_build = ms;
+    return RT_OK;
+}

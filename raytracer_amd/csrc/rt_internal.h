@@ -1,0 +1,126 @@
+// rt_internal.h — device data layout and host-side plumbing shared by the
+// translation units of librt_amd.so (lbvh.hip, trace.hip, rt_shim.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_shim.h"
+
+// The trace arithmetic must round exactly as the reference's scalar C++ does
+// (x86-64 SSE, no fused multiply-add), so contraction is off for every
+// expression in these files; the build also passes -ffp-contract=off.
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------ device records
+
+// Analytic primitive (sphere or plane), 64 B, read wave-uniformly.
+struct DevAnalytic {
+    float px, py, pz, s;          // sphere: centre, radius | plane: normal, offset
+    float s2;                     // sphere: radius*radius (main.cpp:53)
+    int32_t kind, is_light, pad0;
+    float reflect, diffuse, spec, pad1;
+    float cr, cg, cb, pad2;
+};
+
+// Material table entry, 32 B.
+struct DevMaterial {
+    float reflect, diffuse, spec, pad0;
+    float cr, cg, cb, pad1;
+};
+
+// LBVH traversal node, 64 B: both children's boxes live in the parent so one
+// 64-byte fetch decides both.  child >= 0: node index; child < 0: leaf,
+// ~child = first_sorted_triangle * 8 + (count - 1).
+struct BvhNode {
+    float4 xy0;   // child0: lo.x, hi.x, lo.y, hi.y
+    float4 xy1;   // child1: lo.x, hi.x, lo.y, hi.y
+    float4 z01;   // child0: lo.z, hi.z ; child1: lo.z, hi.z
+    int4 ch;      // child0, child1, unused, unused
+};
+
+// Everything a trace kernel needs about the scene (passed by value).
+struct DevScene {
+    const DevAnalytic *analytic;   // [n_analytic], scene order
+    const int32_t *lights;         // [n_lights] analytic ids with is_light, scene order
+    const float4 *tri_mt;          // [n_tris*3] original order: (v1,·) (e1,·) (e2,·)
+    const float4 *tri_n;           // [n_tris] (N.xyz, material index as int bits)
+    const DevMaterial *mats;       // [n_mats]
+    const BvhNode *nodes;          // LBVH, root = 0
+    const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
+    int32_t n_analytic, n_lights, n_tris, accel;
+};
+
+struct DevCamera {
+    float ox, oy, oz;
+    float pitch, off_x, off_y, plane_z;
+};
+
+// Per-frame device counters (zeroed by one hipMemsetAsync per frame).
+struct FrameCounters {
+    unsigned int queue_count[RT_MAX_DEPTH + 2];   // rays queued for each level
+    unsigned int cursor[RT_MAX_DEPTH + 2];        // work-fetch cursor of each level
+    unsigned long long rays_shadow, rays_reflect;
+    unsigned long long box_tests, tri_tests, analytic_tests;
+};
+
+// ------------------------------------------------------------------ host-side state
+
+struct LbvhResult {
+    BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
+    float4 *bvh_tri = nullptr;     // [n_tris*3]
+    int n_nodes = 0, depth = 0, leaf_max = 0;
+    float ms_build = 0.f;
+};
+
+// lbvh.hip: builds the LBVH over tri_mt (device) on `stream`.  Returns RT_* code.
+int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, hipStream_t stream, LbvhResult *out,
+               std::string *err);
+void lbvh_free(LbvhResult *r);
+
+// lbvh.hip: Triangle constructor (main.cpp:104-107) on the device.
+int tri_setup_flat(const float *d_tri_verts, int n_tris, float4 *tri_mt, float4 *tri_n, int mat_index,
+                   hipStream_t stream);
+int tri_setup_indexed(const float *d_verts, int n_verts, const int32_t *d_indices, int n_tris, float4 *tri_mt,
+                      float4 *tri_n, int mat_index, int *d_bad_index_flag, hipStream_t stream);
+
+struct FrameParams {
+    int W, H;
+    rt_rowset rows;
+    int max_depth;
+    int count_tests;
+    int timing;
+    int stack_depth;               // LBVH depth bound used to pick the traversal variant
+};
+
+struct FrameWorkspace {
+    float4 *records = nullptr;     // [(max_depth+1)][n_pixels]: (local colour, hit id bits)
+    float *hit_t = nullptr;        // [n_pixels] level-0 nearest t
+    float4 *queue_o[2] = { nullptr, nullptr };   // ray queues: (origin, pixel index bits)
+    float4 *queue_d[2] = { nullptr, nullptr };   //             (direction, unused)
+    FrameCounters *counters = nullptr;
+    size_t pixels_cap = 0;
+    int levels_cap = 0;
+    // staging outputs for the host-buffer entry point
+    uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr;
+    size_t out_cap = 0;
+    std::vector<hipEvent_t> events;
+};
+
+// trace.hip: enqueue one frame.  Outputs are device pointers (may be null).
+int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws,
+                void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream,
+                int *n_launches, std::string *err);
+int trace_deinterleave(const void *src, void *dst, int W, int H, int band_rows, int n_parts, int rows_per_part,
+                       int bpp, hipStream_t stream);
+
+#define RT_HIP_CHECK(expr, errp)                                                              \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            if (errp) *(errp) = std::string(#expr) + ": " + hipGetErrorString(e__);           \
+            return RT_E_DEVICE;                                                               \
+        }                                                                                     \
+    } while (0)

@@ -1,0 +1,534 @@
+// rt_shim.hip — the C ABI declared in include/rt_shim.h: context, scene upload,
+// workspace management and the render-frame entry points.  No CPU fallback lives
+// here: every entry point either runs the HIP kernels or returns an error.
+#include "rt_internal.h"
+
+#include <string.h>
+
+#include <new>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // scene
+    DevAnalytic *d_analytic = nullptr;
+    int32_t *d_lights = nullptr;
+    int n_analytic = 0, n_lights = 0;
+    float4 *d_tri_mt = nullptr, *d_tri_n = nullptr;
+    int n_tris = 0;
+    DevMaterial *d_mats = nullptr;
+    int n_mats = 0;
+    LbvhResult bvh;
+    // options
+    int opt_accel = 0, opt_count = 0, opt_leaf_max = 4, opt_timing = 1;
+    DevCamera cam;
+    FrameWorkspace ws;
+    // last frame
+    bool frame_valid = false;
+    int last_levels = 0, last_launches = 0, last_accel = 0;
+    uint64_t last_primary = 0;
+};
+
+namespace {
+
+void default_camera(DevCamera *c)   // main.cpp:267-269
+{
+    c->ox = 0.0f; c->oy = 0.0f; c->oz = -5.0f;
+    c->pitch = 0.01f; c->off_x = -4.0f; c->off_y = -4.0f; c->plane_z = 0.0f;
+}
+
+DevMaterial to_dev(const rt_material *m)
+{
+    DevMaterial d;
+    memset(&d, 0, sizeof d);
+    if (m) {
+        d.reflect = m->reflect; d.diffuse = m->diffuse; d.spec = m->spec;
+        d.cr = m->color[0]; d.cg = m->color[1]; d.cb = m->color[2];
+    } else {   // Material(), main.cpp:34
+        d.reflect = 0.0f; d.diffuse = 1.0f; d.spec = 1.0f;
+        d.cr = d.cg = d.cb = 1.0f;
+    }
+    return d;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_triangles(rt_ctx *c)
+{
+    if (c->d_tri_mt) (void)hipFree(c->d_tri_mt);
+    if (c->d_tri_n) (void)hipFree(c->d_tri_n);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    c->d_tri_mt = c->d_tri_n = nullptr;
+    c->d_mats = nullptr;
+    c->n_tris = 0;
+    c->n_mats = 0;
+    lbvh_free(&c->bvh);
+}
+
+void free_workspace(FrameWorkspace &ws)
+{
+    void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32 };
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
+    ws = FrameWorkspace();
+}
+
+int ensure_workspace(rt_ctx *c, size_t pixels, int levels, bool host_outputs)
+{
+    FrameWorkspace &ws = c->ws;
+    if (!ws.counters) {
+        if (hipMalloc((void **)&ws.counters, sizeof(FrameCounters)) != hipSuccess)
+            return fail(RT_E_NOMEM, "hipMalloc(counters) failed");
+    }
+    if (pixels > ws.pixels_cap || levels > ws.levels_cap) {
+        size_t pc = pixels > ws.pixels_cap ? pixels : ws.pixels_cap;
+        int lc = levels > ws.levels_cap ? levels : ws.levels_cap;
+        void *old[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1] };
+        for (void *p : old)
+            if (p) (void)hipFree(p);
+        ws.records = nullptr; ws.hit_t = nullptr;
+        ws.queue_o[0] = ws.queue_o[1] = ws.queue_d[0] = ws.queue_d[1] = nullptr;
+        ws.pixels_cap = 0; ws.levels_cap = 0;
+        hipError_t e = hipMalloc((void **)&ws.records, sizeof(float4) * pc * (size_t)lc);
+        if (e == hipSuccess) e = hipMalloc((void **)&ws.hit_t, sizeof(float) * pc);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc((void **)&ws.queue_o[k], sizeof(float4) * pc);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.queue_d[k], sizeof(float4) * pc);
+        }
+        if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("frame workspace: ") + hipGetErrorString(e));
+        ws.pixels_cap = pc;
+        ws.levels_cap = lc;
+    }
+    if (host_outputs && pixels > ws.out_cap) {
+        void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32 };
+        for (void *p : old)
+            if (p) (void)hipFree(p);
+        ws.out_rgb8 = nullptr; ws.out_id = nullptr; ws.out_rgb32 = nullptr; ws.out_cap = 0;
+        hipError_t e = hipMalloc((void **)&ws.out_rgb8, 3 * pixels);
+        if (e == hipSuccess) e = hipMalloc((void **)&ws.out_id, sizeof(int32_t) * pixels);
+        if (e == hipSuccess) e = hipMalloc((void **)&ws.out_rgb32, sizeof(float) * 3 * pixels);
+        if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("output staging: ") + hipGetErrorString(e));
+        ws.out_cap = pixels;
+    }
+    return RT_OK;
+}
+
+// Decide linear scan vs LBVH for this frame and make sure the LBVH exists when wanted.
+int ensure_accel(rt_ctx *c, int *accel)
+{
+    bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
+    if (c->n_tris < 2) want = false;
+    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max)) {
+        std::string err;
+        int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->stream, &c->bvh, &err);
+        if (rc != RT_OK) return fail(rc, err);
+        if (c->bvh.depth > 64)
+            return fail(RT_E_LIMIT, "LBVH deeper than the 64-entry traversal stack");
+    }
+    *accel = want ? 1 : 0;
+    return RT_OK;
+}
+
+int finish_triangles(rt_ctx *c, int n_tris, const rt_material *mat)
+{
+    DevMaterial m = to_dev(mat);
+    if (hipMalloc((void **)&c->d_mats, sizeof(DevMaterial)) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(mats)");
+    if (hipMemcpyAsync(c->d_mats, &m, sizeof m, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return fail(RT_E_DEVICE, "upload material");
+    c->n_mats = 1;
+    c->n_tris = n_tris;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(RT_E_DEVICE, "triangle set-up failed");
+    int accel = 0;
+    return ensure_accel(c, &accel);
+}
+
+int validate_rows(int W, int H, const rt_rowset *r)
+{
+    if (W <= 0 || H <= 0) return fail(RT_E_INVALID, "W and H must be positive");
+    if (!r || r->band_rows < 1 || r->band_stride < 1 || r->first_band < 0 || r->n_rows < 0)
+        return fail(RT_E_INVALID, "bad rowset");
+    if (r->n_rows > 0) {
+        long long last = r->n_rows - 1;
+        long long y = ((long long)r->first_band + (last / r->band_rows) * r->band_stride) * r->band_rows + last % r->band_rows;
+        if (y >= H) return fail(RT_E_INVALID, "rowset reaches past the last image row");
+    }
+    if ((long long)W * r->n_rows >= (1ll << 31)) return fail(RT_E_LIMIT, "more than 2^31 pixels in one call");
+    return RT_OK;
+}
+
+int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
+                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs)
+{
+    if (int rc = validate_rows(W, H, rows)) return rc;
+    if (max_depth < 0 || max_depth > RT_MAX_DEPTH) return fail(RT_E_INVALID, "max_depth out of range");
+    if (c->n_analytic == 0 && c->n_tris == 0) return fail(RT_E_STATE, "no scene set");
+    c->frame_valid = false;
+    const size_t pixels = (size_t)W * (size_t)rows->n_rows;
+    if (pixels == 0) return RT_OK;
+    if (int rc = ensure_workspace(c, pixels, max_depth + 1, host_outputs)) return rc;
+    int accel = 0;
+    if (int rc = ensure_accel(c, &accel)) return rc;
+
+    DevScene sc;
+    sc.analytic = c->d_analytic; sc.lights = c->d_lights;
+    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
+
+    FrameParams fp;
+    fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
+    fp.count_tests = c->opt_count; fp.timing = c->opt_timing;
+    fp.stack_depth = accel ? c->bvh.depth : 0;
+    if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
+    std::string err;
+    int launches = 0;
+    int rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+    if (rc != RT_OK) return fail(rc, err);
+    c->frame_valid = true;
+    c->last_levels = max_depth + 1;
+    c->last_launches = launches;
+    c->last_accel = accel;
+    c->last_primary = pixels;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+rt_ctx *rt_create(int device_ordinal)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(RT_E_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        fail(RT_E_INVALID, "device ordinal out of range");
+        return nullptr;
+    }
+    rt_ctx *c = new (std::nothrow) rt_ctx();
+    if (!c) { fail(RT_E_NOMEM, "out of host memory"); return nullptr; }
+    c->device = device_ordinal;
+    DeviceGuard g(c->device);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(RT_E_DEVICE, "hipStreamCreate failed");
+        delete c;
+        return nullptr;
+    }
+    default_camera(&c->cam);
+    return c;
+}
+
+void rt_destroy(rt_ctx *c)
+{
+    if (!c) return;
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_triangles(c);
+    free_workspace(c->ws);
+    if (c->d_analytic) (void)hipFree(c->d_analytic);
+    if (c->d_lights) (void)hipFree(c->d_lights);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_set_option(rt_ctx *c, int option, int value)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    switch (option) {
+    case RT_OPT_ACCEL:
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_ACCEL takes 0, 1 or 2");
+        c->opt_accel = value;
+        return RT_OK;
+    case RT_OPT_COUNT_TESTS: c->opt_count = value ? 1 : 0; return RT_OK;
+    case RT_OPT_LEAF_MAX:
+        if (value < 1 || value > 8) return fail(RT_E_INVALID, "RT_OPT_LEAF_MAX takes 1..8");
+        c->opt_leaf_max = value;
+        return RT_OK;
+    case RT_OPT_TIMING: c->opt_timing = value ? 1 : 0; return RT_OK;
+    default: return fail(RT_E_INVALID, "unknown option");
+    }
+}
+
+int rt_set_analytic(rt_ctx *c, const rt_analytic *prims, int n)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (n < 0 || (n > 0 && !prims)) return fail(RT_E_INVALID, "bad analytic array");
+    if (n > RT_MAX_ANALYTIC) return fail(RT_E_LIMIT, "more than RT_MAX_ANALYTIC analytic primitives");
+    std::vector<DevAnalytic> host((size_t)n);
+    std::vector<int32_t> lights;
+    for (int i = 0; i < n; i++) {
+        const rt_analytic &p = prims[i];
+        if (p.kind != RT_SPHERE && p.kind != RT_PLANE) return fail(RT_E_INVALID, "unknown analytic kind");
+        if (p.is_light && p.kind != RT_SPHERE)
+            return fail(RT_E_INVALID, "only spheres can be lights (the reference reads a light's position through Sphere*)");
+        DevAnalytic d;
+        memset(&d, 0, sizeof d);
+        d.px = p.p[0]; d.py = p.p[1]; d.pz = p.p[2]; d.s = p.s;
+        d.s2 = p.s * p.s;   // Sphere::radiusSq, main.cpp:53
+        d.kind = p.kind; d.is_light = p.is_light ? 1 : 0;
+        d.reflect = p.mat.reflect; d.diffuse = p.mat.diffuse; d.spec = p.mat.spec;
+        d.cr = p.mat.color[0]; d.cg = p.mat.color[1]; d.cb = p.mat.color[2];
+        host[(size_t)i] = d;
+        if (p.is_light) lights.push_back(i);
+    }
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_analytic) (void)hipFree(c->d_analytic);
+    if (c->d_lights) (void)hipFree(c->d_lights);
+    c->d_analytic = nullptr; c->d_lights = nullptr; c->n_analytic = 0; c->n_lights = 0;
+    if (hipMalloc((void **)&c->d_analytic, sizeof(DevAnalytic) * (size_t)(n ? n : 1)) != hipSuccess ||
+        hipMalloc((void **)&c->d_lights, sizeof(int32_t) * (lights.size() ? lights.size() : 1)) != hipSuccess)
+        return fail(RT_E_NOMEM, "hipMalloc(analytic) failed");
+    if (n && hipMemcpy(c->d_analytic, host.data(), sizeof(DevAnalytic) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(RT_E_DEVICE, "upload analytic primitives");
+    if (!lights.empty() &&
+        hipMemcpy(c->d_lights, lights.data(), sizeof(int32_t) * lights.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(RT_E_DEVICE, "upload light list");
+    c->n_analytic = n;
+    c->n_lights = (int)lights.size();
+    return RT_OK;
+}
+
+int rt_set_triangles(rt_ctx *c, const float *tri_verts, int n_tris, const rt_material *mat)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (n_tris < 0 || (n_tris > 0 && !tri_verts)) return fail(RT_E_INVALID, "bad triangle array");
+    if ((long long)n_tris * 8 >= (1ll << 31)) return fail(RT_E_LIMIT, "too many triangles");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_triangles(c);
+    if (n_tris == 0) return RT_OK;
+    float *d_v = nullptr;
+    if (hipMalloc((void **)&d_v, sizeof(float) * 9 * (size_t)n_tris) != hipSuccess ||
+        hipMalloc((void **)&c->d_tri_mt, sizeof(float4) * 3 * (size_t)n_tris) != hipSuccess ||
+        hipMalloc((void **)&c->d_tri_n, sizeof(float4) * (size_t)n_tris) != hipSuccess) {
+        if (d_v) (void)hipFree(d_v);
+        free_triangles(c);
+        return fail(RT_E_NOMEM, "hipMalloc(triangles) failed");
+    }
+    int rc = RT_OK;
+    if (hipMemcpyAsync(d_v, tri_verts, sizeof(float) * 9 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(RT_E_DEVICE, "upload triangle vertices");
+    if (rc == RT_OK && tri_setup_flat(d_v, n_tris, c->d_tri_mt, c->d_tri_n, 0, c->stream) != RT_OK)
+        rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
+    if (rc == RT_OK) rc = finish_triangles(c, n_tris, mat);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_v);
+    if (rc != RT_OK) free_triangles(c);
+    return rc;
+}
+
+int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indices, int n_indices, const rt_material *mat)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (n_verts < 0 || n_indices < 0 || (n_verts > 0 && !verts) || (n_indices > 0 && !indices))
+        return fail(RT_E_INVALID, "bad mesh arrays");
+    // main.cpp:228 steps i += 3 and reads inds[i+1], inds[i+2]: a count that is not a
+    // multiple of 3 reads past the vector there; refuse it here.
+    if (n_indices % 3) return fail(RT_E_INVALID, "index count is not a multiple of 3");
+    const int n_tris = n_indices / 3;
+    if ((long long)n_tris * 8 >= (1ll << 31)) return fail(RT_E_LIMIT, "too many triangles");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_triangles(c);
+    if (n_tris == 0) return RT_OK;
+    if (n_verts == 0) return fail(RT_E_INVALID, "indices without vertices");
+    float *d_v = nullptr;
+    int32_t *d_i = nullptr;
+    int *d_bad = nullptr;
+    hipError_t e = hipMalloc((void **)&d_v, sizeof(float) * 3 * (size_t)n_verts);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_i, sizeof(int32_t) * (size_t)n_indices);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bad, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tri_mt, sizeof(float4) * 3 * (size_t)n_tris);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tri_n, sizeof(float4) * (size_t)n_tris);
+    int rc = RT_OK;
+    if (e != hipSuccess) rc = fail(RT_E_NOMEM, "hipMalloc(mesh) failed");
+    int bad = 0;
+    if (rc == RT_OK) {
+        e = hipMemcpyAsync(d_v, verts, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_i, indices, sizeof(int32_t) * (size_t)n_indices, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), c->stream);
+        if (e != hipSuccess) rc = fail(RT_E_DEVICE, "upload mesh");
+    }
+    if (rc == RT_OK && tri_setup_indexed(d_v, n_verts, d_i, n_tris, c->d_tri_mt, c->d_tri_n, 0, d_bad, c->stream) != RT_OK)
+        rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
+    if (rc == RT_OK && hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(RT_E_DEVICE, "read index check");
+    if (rc == RT_OK) rc = finish_triangles(c, n_tris, mat);
+    if (rc == RT_OK && bad) rc = fail(RT_E_INVALID, "vertex index out of range");
+    (void)hipStreamSynchronize(c->stream);
+    if (d_v) (void)hipFree(d_v);
+    if (d_i) (void)hipFree(d_i);
+    if (d_bad) (void)hipFree(d_bad);
+    if (rc != RT_OK) free_triangles(c);
+    return rc;
+}
+
+int rt_set_triangle_materials(rt_ctx *c, const rt_material *mats, int n_mats, const int32_t *tri_material, int n_tris)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (!mats || n_mats < 1 || !tri_material) return fail(RT_E_INVALID, "bad material arrays");
+    if (n_tris != c->n_tris || c->n_tris == 0) return fail(RT_E_STATE, "triangle count does not match the loaded mesh");
+    for (int k = 0; k < n_tris; k++)
+        if (tri_material[k] < 0 || tri_material[k] >= n_mats) return fail(RT_E_INVALID, "material index out of range");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<DevMaterial> hm((size_t)n_mats);
+    for (int k = 0; k < n_mats; k++) hm[(size_t)k] = to_dev(&mats[k]);
+    // tri_n.w carries the material index: patch it in place.
+    std::vector<float4> hn((size_t)n_tris);
+    if (hipMemcpy(hn.data(), c->d_tri_n, sizeof(float4) * (size_t)n_tris, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(RT_E_DEVICE, "read normals");
+    for (int k = 0; k < n_tris; k++) memcpy(&hn[(size_t)k].w, &tri_material[k], sizeof(int32_t));
+    DevMaterial *nm = nullptr;
+    if (hipMalloc((void **)&nm, sizeof(DevMaterial) * (size_t)n_mats) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(mats)");
+    if (hipMemcpy(nm, hm.data(), sizeof(DevMaterial) * (size_t)n_mats, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_tri_n, hn.data(), sizeof(float4) * (size_t)n_tris, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(nm);
+        return fail(RT_E_DEVICE, "upload materials");
+    }
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    c->d_mats = nm;
+    c->n_mats = n_mats;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *c, const rt_camera *cam)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (!cam) { default_camera(&c->cam); return RT_OK; }
+    c->cam.ox = cam->origin[0]; c->cam.oy = cam->origin[1]; c->cam.oz = cam->origin[2];
+    c->cam.pitch = cam->pitch; c->cam.off_x = cam->off_x; c->cam.off_y = cam->off_y; c->cam.plane_z = cam->plane_z;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint8_t *rgb8, int32_t *hit_id, float *rgb32)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
+    DeviceGuard g(c->device);
+    rt_rowset rows = { y0, 1, 1, y1 - y0 };
+    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true);
+    if (rc != RT_OK) return rc;
+    const size_t pixels = (size_t)W * (size_t)(y1 - y0);
+    hipError_t e = hipSuccess;
+    if (pixels) {
+        if (rgb8) e = hipMemcpyAsync(rgb8, c->ws.out_rgb8, 3 * pixels, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && hit_id)
+            e = hipMemcpyAsync(hit_id, c->ws.out_id, sizeof(int32_t) * pixels, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && rgb32)
+            e = hipMemcpyAsync(rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_rows_device(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
+                          void *d_rgb32, void *d_hit_t, void *stream)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    DeviceGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return render_common(c, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, false);
+}
+
+int rt_deinterleave_bands(rt_ctx *c, const void *d_src, void *d_dst, int W, int H, int band_rows, int n_parts,
+                          int rows_per_part, int bytes_per_pixel, void *stream)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (!d_src || !d_dst || W <= 0 || H <= 0 || band_rows < 1 || n_parts < 1 || rows_per_part < 0)
+        return fail(RT_E_INVALID, "bad de-interleave arguments");
+    if (bytes_per_pixel != 3 && bytes_per_pixel != 4 && bytes_per_pixel != 12)
+        return fail(RT_E_INVALID, "bytes_per_pixel must be 3, 4 or 12");
+    // every image row must exist inside its part
+    const int n_bands = (H + band_rows - 1) / band_rows;
+    const int bands_per_part = (n_bands + n_parts - 1) / n_parts;
+    if (bands_per_part * band_rows > rows_per_part) return fail(RT_E_INVALID, "rows_per_part too small for this split");
+    DeviceGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (trace_deinterleave(d_src, d_dst, W, H, band_rows, n_parts, rows_per_part, bytes_per_pixel, s) != RT_OK)
+        return fail(RT_E_DEVICE, "de-interleave launch failed");
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx *c)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    DeviceGuard g(c->device);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(RT_E_DEVICE, hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out)
+{
+    if (!c || !out) return fail(RT_E_INVALID, "null argument");
+    DeviceGuard g(c->device);
+    memset(out, 0, sizeof *out);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(RT_E_DEVICE, hipGetErrorString(e));
+    out->n_analytic = c->n_analytic;
+    out->n_triangles = c->n_tris;
+    out->bvh_nodes = c->bvh.n_nodes;
+    out->bvh_depth = c->bvh.depth;
+    out->bvh_leaf_max = c->bvh.leaf_max;
+    out->ms_build = c->bvh.ms_build;
+    if (!c->frame_valid) return RT_OK;
+    FrameCounters fc;
+    if (hipMemcpy(&fc, c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(RT_E_DEVICE, "read frame counters");
+    out->rays_primary = c->last_primary;
+    out->rays_shadow = fc.rays_shadow;
+    out->rays_reflect = fc.rays_reflect;
+    out->box_tests = fc.box_tests;
+    out->tri_tests = fc.tri_tests;
+    out->analytic_tests = fc.analytic_tests;
+    out->n_launches = c->last_launches;
+    out->accel = c->last_accel;
+    if (c->opt_timing && (int)c->ws.events.size() >= c->last_levels + 2) {
+        // events: [start] (bounce level k) x levels [after each] (resolve) [end]
+        float ms = 0.f, tr = 0.f;
+        for (int k = 0; k < c->last_levels; k++) {
+            if (hipEventElapsedTime(&ms, c->ws.events[(size_t)k], c->ws.events[(size_t)k + 1]) == hipSuccess) tr += ms;
+        }
+        out->ms_trace = tr;
+        if (hipEventElapsedTime(&ms, c->ws.events[(size_t)c->last_levels], c->ws.events[(size_t)c->last_levels + 1]) == hipSuccess)
+            out->ms_resolve = ms;
+        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)c->last_levels + 1]) == hipSuccess)
+            out->ms_frame = ms;
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

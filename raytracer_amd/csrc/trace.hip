@@ -1,0 +1,615 @@
+// trace.hip — the per-pixel trace path as wave64 HIP kernels for gfx950.
+//
+// What it replaces (Raytracer/main.cpp): the pixel loop 262-277 and everything it
+// calls — camera ray 267-270, raytrace() 144-217 with Sphere/Plane/Triangle
+// Raycast 56-68 / 84-92 / 109-129, hard shadows 177-188, N·L diffuse 191-195,
+// pow-20 specular 198-204, mirror recursion 208-213, clamp + 8-bit store 139-142, 273.
+//
+// Shape of the computation on the GPU:
+//   * The recursion becomes one launch per bounce level.  k_bounce<level> takes a
+//     compacted queue of live rays (level 0 generates camera rays in registers),
+//     finds the nearest primitive, casts the shadow rays, evaluates the local
+//     shading term and writes one 16-byte record (local colour, hit id) per pixel
+//     and level.  Rays that reflect are appended to the next level's queue with a
+//     wave ballot + one atomic per wave.
+//   * k_resolve folds the per-level records back together deepest-first,
+//     col_k = local_k + (col_{k+1} * Mc_k) * kr_k, which is exactly the order in which
+//     the reference's recursion unwinds (main.cpp:211-212), then clamps/quantises.
+//   * Waves are persistent: each wave pulls 64-ray batches from a per-level cursor, so
+//     launch size does not depend on queue lengths known only on the device.
+//
+// Float discipline: no contraction, IEEE divide/sqrt, operand order as in maths.h,
+// so every value except powf is bit-equal to the reference's x86 results.
+#include "rt_internal.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int NODE_SENTINEL = 0x7fffffff;
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 mk(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 f3(float4 v) { return mk(v.x, v.y, v.z); }
+__device__ __forceinline__ F3 muls(F3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }            // maths.h:102
+__device__ __forceinline__ F3 add(F3 a, F3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }           // maths.h:110
+__device__ __forceinline__ F3 mulv(F3 a, F3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }          // maths.h:117
+__device__ __forceinline__ F3 sub(F3 a, F3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }           // maths.h:132
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // maths.h:140
+__device__ __forceinline__ F3 normalize(F3 a)                                                           // maths.h:158-162
+{
+    float len = sqrtf(dot(a, a));
+    return mk(a.x / len, a.y / len, a.z / len);
+}
+__device__ __forceinline__ F3 cross(F3 a, F3 b)                                                         // maths.h:165-172
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// powf(x, 20.0f) for x > 0 (main.cpp:203).  Five double multiplications carry a
+// relative error below 1e-15, so the float result is the correctly rounded power
+// except within that distance of a rounding boundary.
+__device__ __forceinline__ float pow20(float x)
+{
+    double a = (double)x;
+    double a2 = a * a, a4 = a2 * a2, a5 = a4 * a, a10 = a5 * a5;
+    return (float)(a10 * a10);
+}
+
+// ------------------------------------------------------------------ intersectors
+__device__ __forceinline__ bool sphere_raycast(const DevAnalytic &s, F3 o, F3 d, float &t)              // main.cpp:56-68
+{
+    F3 l = sub(mk(s.px, s.py, s.pz), o);
+    float distToCenter = dot(l, d);
+    if (distToCenter < 0.0f) return false;
+    float distToIntersectSq = dot(l, l) - distToCenter * distToCenter;
+    if (distToIntersectSq > s.s2) return false;
+    t = distToCenter - sqrtf(s.s2 - distToIntersectSq);
+    return true;
+}
+
+__device__ __forceinline__ bool plane_raycast(const DevAnalytic &p, F3 o, F3 d, float &t)               // main.cpp:84-92
+{
+    F3 n = mk(p.px, p.py, p.pz);
+    float ldotn = dot(n, d);
+    if (ldotn == 0.0f) return false;
+    t = (p.s - dot(n, o)) / ldotn;
+    return t > 0.0f;
+}
+
+__device__ __forceinline__ bool tri_raycast(F3 v1, F3 e1, F3 e2, F3 o, F3 d, float &t)                  // main.cpp:109-129
+{
+    F3 P = cross(d, e2);
+    float det = dot(e1, P);
+    if (det > -0.0001f && det < 0.0001f) return false;
+    float invdet = 1.0f / det;
+    F3 T = sub(o, v1);
+    float u = dot(T, P) * invdet;
+    if (u < 0.0f || u > 1.0f) return false;
+    F3 Q = cross(T, e1);
+    float v = dot(d, Q) * invdet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(e2, Q) * invdet;
+    return t > 0.0001f;
+}
+
+struct Tally { unsigned box, tri, analytic; };
+
+// ------------------------------------------------------------------ nearest hit (main.cpp:147-156)
+// `nearest > t` in scene order keeps the lowest id among equal distances; out of
+// order (LBVH) the same winner is selected explicitly by (t, id).
+template <bool COUNT>
+__device__ __forceinline__ void analytic_nearest(const DevScene &sc, F3 o, F3 d, float &best_t, int &best_id, Tally &tl)
+{
+    for (int i = 0; i < sc.n_analytic; i++) {
+        const DevAnalytic a = sc.analytic[i];
+        float t;
+        bool h = (a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t);
+        if (h && best_t > t) { best_t = t; best_id = i; }
+    }
+    if (COUNT) tl.analytic += (unsigned)sc.n_analytic;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void brute_nearest(const DevScene &sc, F3 o, F3 d, float &best_t, int &best_id, Tally &tl)
+{
+    for (int k = 0; k < sc.n_tris; k++) {
+        F3 v1 = f3(sc.tri_mt[3 * k]), e1 = f3(sc.tri_mt[3 * k + 1]), e2 = f3(sc.tri_mt[3 * k + 2]);
+        float t;
+        if (tri_raycast(v1, e1, e2, o, d, t) && best_t > t) { best_t = t; best_id = sc.n_analytic + k; }
+    }
+    if (COUNT) tl.tri += (unsigned)sc.n_tris;
+}
+
+// Slab test of one child box against the ray interval [0, tmax].
+__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, F3 o, F3 inv,
+                                     float tmax, float &tnear)
+{
+    float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// stack: this lane's column of the block's LDS stack, element k at stack[k*BLOCK].
+template <bool COUNT>
+__device__ __forceinline__ void bvh_nearest(const DevScene &sc, F3 o, F3 d, bool live, float &best_t, int &best_id,
+                                            int *stack, int stack_cap, Tally &tl)
+{
+    F3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 1;
+    stack[0] = NODE_SENTINEL;
+    int node = live ? 0 : NODE_SENTINEL;
+    while (node != NODE_SENTINEL) {
+        if (node >= 0) {
+            const BvhNode *np = sc.nodes + node;
+            float4 xy0 = np->xy0, xy1 = np->xy1, z01 = np->z01;
+            int4 ch = np->ch;
+            float tn0, tn1;
+            bool h0 = slab(xy0.x, xy0.y, xy0.z, xy0.w, z01.x, z01.y, o, inv, best_t, tn0);
+            bool h1 = slab(xy1.x, xy1.y, xy1.z, xy1.w, z01.z, z01.w, o, inv, best_t, tn1);
+            if (COUNT) tl.box += 2;
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int nearc = swap ? ch.y : ch.x, farc = swap ? ch.x : ch.y;
+                if (sp < stack_cap) { stack[sp * BLOCK] = farc; sp++; }
+                node = nearc;
+                continue;
+            }
+            if (h0) { node = ch.x; continue; }
+            if (h1) { node = ch.y; continue; }
+        } else {
+            int leaf = ~node, first = leaf >> 3, cnt = (leaf & 7) + 1;
+            for (int k = 0; k < cnt; k++) {
+                float4 a = sc.bvh_tri[3 * (size_t)(first + k)];
+                F3 e1 = f3(sc.bvh_tri[3 * (size_t)(first + k) + 1]), e2 = f3(sc.bvh_tri[3 * (size_t)(first + k) + 2]);
+                float t;
+                if (tri_raycast(f3(a), e1, e2, o, d, t)) {
+                    int id = sc.n_analytic + __float_as_int(a.w);
+                    if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
+                }
+            }
+            if (COUNT) tl.tri += (unsigned)cnt;
+        }
+        sp--;
+        node = stack[sp * BLOCK];
+    }
+}
+
+// ------------------------------------------------------------------ shadow query (main.cpp:181-188)
+// True when ANY non-light primitive's Raycast accepts the ray, at any distance.
+template <bool COUNT>
+__device__ __forceinline__ bool analytic_occluded(const DevScene &sc, F3 o, F3 d, Tally &tl)
+{
+    for (int i = 0; i < sc.n_analytic; i++) {
+        const DevAnalytic a = sc.analytic[i];
+        if (a.is_light) continue;
+        float t;
+        if (COUNT) tl.analytic++;
+        if ((a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t)) return true;
+    }
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool brute_occluded(const DevScene &sc, F3 o, F3 d, Tally &tl)
+{
+    for (int k = 0; k < sc.n_tris; k++) {
+        F3 v1 = f3(sc.tri_mt[3 * k]), e1 = f3(sc.tri_mt[3 * k + 1]), e2 = f3(sc.tri_mt[3 * k + 2]);
+        float t;
+        if (COUNT) tl.tri++;
+        if (tri_raycast(v1, e1, e2, o, d, t)) return true;
+    }
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool bvh_occluded(const DevScene &sc, F3 o, F3 d, bool live, int *stack, int stack_cap, Tally &tl)
+{
+    F3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 1;
+    stack[0] = NODE_SENTINEL;
+    int node = live ? 0 : NODE_SENTINEL;
+    bool occ = false;
+    while (node != NODE_SENTINEL) {
+        if (node >= 0) {
+            const BvhNode *np = sc.nodes + node;
+            float4 xy0 = np->xy0, xy1 = np->xy1, z01 = np->z01;
+            int4 ch = np->ch;
+            float tn0, tn1;
+            bool h0 = slab(xy0.x, xy0.y, xy0.z, xy0.w, z01.x, z01.y, o, inv, FLT_MAX, tn0);
+            bool h1 = slab(xy1.x, xy1.y, xy1.z, xy1.w, z01.z, z01.w, o, inv, FLT_MAX, tn1);
+            if (COUNT) tl.box += 2;
+            if (h0 && h1) {
+                if (sp < stack_cap) { stack[sp * BLOCK] = ch.y; sp++; }
+                node = ch.x;
+                continue;
+            }
+            if (h0) { node = ch.x; continue; }
+            if (h1) { node = ch.y; continue; }
+        } else {
+            int leaf = ~node, first = leaf >> 3, cnt = (leaf & 7) + 1;
+            for (int k = 0; k < cnt; k++) {
+                F3 v1 = f3(sc.bvh_tri[3 * (size_t)(first + k)]);
+                F3 e1 = f3(sc.bvh_tri[3 * (size_t)(first + k) + 1]), e2 = f3(sc.bvh_tri[3 * (size_t)(first + k) + 2]);
+                float t;
+                if (tri_raycast(v1, e1, e2, o, d, t)) occ = true;
+            }
+            if (COUNT) tl.tri += (unsigned)cnt;
+            if (occ) break;
+        }
+        sp--;
+        node = stack[sp * BLOCK];
+    }
+    return occ;
+}
+
+// ------------------------------------------------------------------ bounce kernel
+struct BounceArgs {
+    DevScene sc;
+    DevCamera cam;
+    int W, n_rows, n_pixels;
+    rt_rowset rows;
+    int level, max_depth;
+    unsigned int n_slots;            // level 0: padded 8x8-tile slot count
+    float4 *records;                 // [level][pixel]
+    float *hit_t;                    // level 0 only, may be null
+    const float4 *q_in_o, *q_in_d;   // level > 0
+    float4 *q_out_o, *q_out_d;
+    FrameCounters *counters;
+    int stack_cap;
+};
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+template <int ACCEL, bool PRIMARY, bool COUNT, int STACK>
+__global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
+{
+    __shared__ int s_stack[(ACCEL ? (STACK + 1) : 1) * BLOCK];
+    int *stack = s_stack + threadIdx.x;
+    const DevScene &sc = A.sc;
+    const int lane = threadIdx.x & 63;
+    const unsigned int n = PRIMARY ? A.n_slots : A.counters->queue_count[A.level];
+    Tally tl = { 0u, 0u, 0u };
+    unsigned int n_shadow = 0, n_reflect = 0;
+
+    for (;;) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&A.counters->cursor[A.level], 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const unsigned int slot = base + (unsigned)lane;
+
+        // ---- this lane's ray
+        bool live;
+        int pixel;
+        F3 o, d;
+        if (PRIMARY) {
+            const int tiles_per_row = (A.W + 7) >> 3;
+            const int tile = (int)(slot >> 6), w = (int)(slot & 63u);
+            const int x = (tile % tiles_per_row) * 8 + (w & 7);
+            const int r = (tile / tiles_per_row) * 8 + (w >> 3);
+            live = x < A.W && r < A.n_rows;
+            pixel = r * A.W + x;
+            const int y = (A.rows.first_band + (r / A.rows.band_rows) * A.rows.band_stride) * A.rows.band_rows +
+                          r % A.rows.band_rows;
+            o = mk(A.cam.ox, A.cam.oy, A.cam.oz);                               // main.cpp:267
+            float offsetX = (float)x * A.cam.pitch + A.cam.off_x;               // main.cpp:268
+            float offsetY = (float)y * A.cam.pitch + A.cam.off_y;               // main.cpp:269
+            d = normalize(sub(mk(offsetX, offsetY, A.cam.plane_z), o));         // main.cpp:270
+        } else {
+            live = slot < n;
+            float4 qo = live ? A.q_in_o[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 qd = live ? A.q_in_d[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+            o = f3(qo);
+            d = f3(qd);
+            pixel = __float_as_int(qo.w);
+        }
+
+        // ---- nearest hit
+        float best_t = FLT_MAX;
+        int best_id = -1;
+        if (live) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+        if (ACCEL == 1) {
+            bvh_nearest<COUNT>(sc, o, d, live, best_t, best_id, stack, A.stack_cap + 1, tl);
+        } else if (live) {
+            brute_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+        }
+
+        // ---- surface
+        const bool hit = live && best_id >= 0;
+        F3 pos = mk(0.f, 0.f, 0.f), N = mk(0.f, 0.f, 1.f), Mc = mk(0.f, 0.f, 0.f);
+        float kr = 0.f, kd = 0.f, ks = 0.f;
+        bool emissive = false;
+        if (hit) {
+            pos = add(o, muls(d, best_t));                                      // main.cpp:163
+            if (best_id < sc.n_analytic) {
+                const DevAnalytic a = sc.analytic[best_id];
+                N = (a.kind == RT_SPHERE) ? normalize(sub(pos, mk(a.px, a.py, a.pz)))   // main.cpp:72
+                                          : mk(a.px, a.py, a.pz);                       // main.cpp:96
+                Mc = mk(a.cr, a.cg, a.cb);
+                kr = a.reflect; kd = a.diffuse; ks = a.spec;
+                emissive = a.is_light != 0;
+            } else {
+                float4 tn = sc.tri_n[best_id - sc.n_analytic];                  // main.cpp:133
+                N = f3(tn);
+                const DevMaterial m = sc.mats[__float_as_int(tn.w)];
+                Mc = mk(m.cr, m.cg, m.cb);
+                kr = m.reflect; kd = m.diffuse; ks = m.spec;
+            }
+        }
+
+        // ---- local shading (main.cpp:166-205)
+        F3 col = mk(0.f, 0.f, 0.f);
+        const bool lit = hit && !emissive;
+        if (hit && emissive) col = Mc;                                          // main.cpp:166-167
+        if (lit) n_shadow += (unsigned)sc.n_lights;
+        for (int li = 0; li < sc.n_lights; li++) {                              // main.cpp:170-173
+            const DevAnalytic lt = sc.analytic[sc.lights[li]];
+            F3 L = mk(0.f, 0.f, 1.f), so = pos;
+            if (lit) {
+                L = normalize(sub(mk(lt.px, lt.py, lt.pz), pos));               // main.cpp:178
+                so = add(pos, muls(L, 0.01f));                                  // main.cpp:179
+            }
+            bool occ = false;
+            if (lit) occ = analytic_occluded<COUNT>(sc, so, L, tl);
+            if (ACCEL == 1) {
+                bool go = lit && !occ;
+                if (bvh_occluded<COUNT>(sc, so, L, go, stack, A.stack_cap + 1, tl)) occ = true;
+            } else if (lit && !occ) {
+                occ = brute_occluded<COUNT>(sc, so, L, tl);
+            }
+            if (lit) {
+                const float shade = occ ? 0.0f : 1.0f;                          // main.cpp:175, 185
+                const F3 Lc = mk(lt.cr, lt.cg, lt.cb);
+                if (kd > 0.0f) {                                                // main.cpp:191-195
+                    float diffuse = dot(N, L) * kd;
+                    col = add(col, muls(muls(mulv(Lc, Mc), diffuse), shade));
+                }
+                if (ks > 0.0f) {                                                // main.cpp:198-204
+                    F3 R = sub(L, muls(muls(N, dot(L, N)), 2.0f));
+                    float dt = dot(d, R);
+                    if (dt > 0.0f)
+                        col = add(col, muls(muls(muls(mulv(Lc, Mc), pow20(dt)), ks), shade));
+                }
+            }
+        }
+
+        // ---- record + reflection ray (main.cpp:208-211)
+        if (live) {
+            A.records[(size_t)A.level * (size_t)A.n_pixels + (size_t)pixel] =
+                make_float4(col.x, col.y, col.z, __int_as_float(best_id));
+            if (PRIMARY && A.hit_t) A.hit_t[pixel] = best_t;
+        }
+        const bool spawn = lit && kr > 0.0f && A.level < A.max_depth;
+        const unsigned long long mask = __ballot(spawn);
+        if (mask) {
+            unsigned int qbase = 0;
+            if (lane == 0) qbase = atomicAdd(&A.counters->queue_count[A.level + 1], (unsigned)__popcll(mask));
+            qbase = __shfl(qbase, 0);
+            if (spawn) {
+                F3 R = sub(d, muls(muls(N, 2.0f), dot(d, N)));                  // main.cpp:210
+                unsigned int dst = qbase + (unsigned)__popcll(mask & lanemask_lt());
+                A.q_out_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(pixel));   // origin is pos itself
+                A.q_out_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
+                n_reflect++;
+            }
+        }
+    }
+
+    // ---- ray / test counters: wave reduce, one atomic per wave
+    unsigned int vals[5] = { n_shadow, n_reflect, tl.box, tl.tri, tl.analytic };
+    const int nv = COUNT ? 5 : 2;
+    for (int k = 0; k < nv; k++) {
+        unsigned long long v = vals[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && v) {
+            unsigned long long *dst = k == 0 ? &A.counters->rays_shadow
+                                    : k == 1 ? &A.counters->rays_reflect
+                                    : k == 2 ? &A.counters->box_tests
+                                    : k == 3 ? &A.counters->tri_tests : &A.counters->analytic_tests;
+            atomicAdd(dst, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+struct ResolveArgs {
+    DevScene sc;
+    int n_pixels, max_depth;
+    const float4 *records;
+    uint8_t *rgb8;      // may be null
+    int32_t *hit_id;    // may be null
+    float *rgb32;       // may be null
+};
+
+__device__ __forceinline__ float clamp01(float f) { return f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f); }   // main.cpp:139-142
+
+// (char)(clamp01(c)*255.0f) as the reference's Debug build evaluates it (main.cpp:273):
+// truncate toward zero, keep the low byte; NaN converts to the low byte of INT_MIN = 0.
+__device__ __forceinline__ uint8_t quantise(float c)
+{
+    float f = clamp01(c) * 255.0f;
+    return (f == f) ? (uint8_t)(int)f : (uint8_t)0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(ResolveArgs A)
+{
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= A.n_pixels) return;
+    const DevScene &sc = A.sc;
+    // Find the deepest level that exists for this pixel: a level k+1 record exists
+    // iff the level-k hit reflected (same test as the spawn in k_bounce).
+    int last = 0;
+    int id0 = -1;
+    for (int k = 0;; k++) {
+        float4 r = A.records[(size_t)k * (size_t)A.n_pixels + (size_t)p];
+        int id = __float_as_int(r.w);
+        if (k == 0) id0 = id;
+        last = k;
+        if (id < 0 || k >= A.max_depth) break;
+        float kr;
+        bool emissive;
+        if (id < sc.n_analytic) { kr = sc.analytic[id].reflect; emissive = sc.analytic[id].is_light != 0; }
+        else { kr = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)].reflect; emissive = false; }
+        if (emissive || !(kr > 0.0f)) break;
+    }
+    float4 r = A.records[(size_t)last * (size_t)A.n_pixels + (size_t)p];
+    F3 col = mk(r.x, r.y, r.z);
+    for (int k = last - 1; k >= 0; k--) {
+        float4 rk = A.records[(size_t)k * (size_t)A.n_pixels + (size_t)p];
+        int id = __float_as_int(rk.w);
+        F3 Mc;
+        float kr;
+        if (id < sc.n_analytic) {
+            const DevAnalytic a = sc.analytic[id];
+            Mc = mk(a.cr, a.cg, a.cb); kr = a.reflect;
+        } else {
+            const DevMaterial m = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)];
+            Mc = mk(m.cr, m.cg, m.cb); kr = m.reflect;
+        }
+        col = add(mk(rk.x, rk.y, rk.z), muls(mulv(col, Mc), kr));               // main.cpp:212
+    }
+    if (A.rgb32) { A.rgb32[3 * (size_t)p] = col.x; A.rgb32[3 * (size_t)p + 1] = col.y; A.rgb32[3 * (size_t)p + 2] = col.z; }
+    if (A.rgb8) {                                                               // main.cpp:273
+        A.rgb8[3 * (size_t)p] = quantise(col.x);
+        A.rgb8[3 * (size_t)p + 1] = quantise(col.y);
+        A.rgb8[3 * (size_t)p + 2] = quantise(col.z);
+    }
+    if (A.hit_id) A.hit_id[p] = id0;
+}
+
+// ------------------------------------------------------------------ band de-interleave (after the gather)
+__global__ void k_deinterleave(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int band_rows,
+                               int n_parts, int rows_per_part, int bpp)
+{
+    // one thread per destination byte of the W x H image
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t row_bytes = (size_t)W * bpp;
+    if (i >= row_bytes * (size_t)H) return;
+    int y = (int)(i / row_bytes);
+    size_t xb = i % row_bytes;
+    int band = y / band_rows, part = band % n_parts, local_band = band / n_parts;
+    int r = local_band * band_rows + y % band_rows;
+    dst[i] = src[((size_t)part * rows_per_part + r) * row_bytes + xb];
+}
+
+template <int ACCEL, bool PRIMARY, bool COUNT, int STACK>
+void launch_bounce(const BounceArgs &a, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_bounce<ACCEL, PRIMARY, COUNT, STACK>), dim3(grid), dim3(BLOCK), 0, stream, a);
+}
+
+template <int ACCEL, int STACK>
+void launch_bounce_sel(const BounceArgs &a, bool primary, bool count, int grid, hipStream_t stream)
+{
+    if (primary) {
+        if (count) launch_bounce<ACCEL, true, true, STACK>(a, grid, stream);
+        else launch_bounce<ACCEL, true, false, STACK>(a, grid, stream);
+    } else {
+        if (count) launch_bounce<ACCEL, false, true, STACK>(a, grid, stream);
+        else launch_bounce<ACCEL, false, false, STACK>(a, grid, stream);
+    }
+}
+
+int g_num_cus = 0;
+
+}  // namespace
+
+int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
+                void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int *n_launches, std::string *err)
+{
+    const int n_rows = fp.rows.n_rows;
+    const int n_pixels = fp.W * n_rows;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RT_HIP_CHECK(hipGetDevice(&dev), err);
+        RT_HIP_CHECK(hipGetDeviceProperties(&prop, dev), err);
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(ws.counters, 0, sizeof(FrameCounters), stream), err);
+
+    BounceArgs a;
+    a.sc = scene;
+    a.cam = cam;
+    a.W = fp.W; a.n_rows = n_rows; a.n_pixels = n_pixels;
+    a.rows = fp.rows;
+    a.max_depth = fp.max_depth;
+    const int tiles = ((fp.W + 7) / 8) * ((n_rows + 7) / 8);
+    a.n_slots = (unsigned)tiles * 64u;
+    a.records = ws.records;
+    a.hit_t = (float *)d_hit_t;
+    a.counters = ws.counters;
+    a.stack_cap = fp.stack_depth;
+
+    const bool timing = fp.timing != 0;
+    size_t ev = 0;
+    auto stamp = [&]() -> int {
+        if (!timing) return RT_OK;
+        if (ev >= ws.events.size()) {
+            hipEvent_t e;
+            RT_HIP_CHECK(hipEventCreate(&e), err);
+            ws.events.push_back(e);
+        }
+        RT_HIP_CHECK(hipEventRecord(ws.events[ev++], stream), err);
+        return RT_OK;
+    };
+
+    int launches = 0;
+    const int full_grid = g_num_cus * 8;
+    if (int rc = stamp()) return rc;
+    for (int level = 0; level <= fp.max_depth; level++) {
+        a.level = level;
+        a.q_in_o = ws.queue_o[level & 1];
+        a.q_in_d = ws.queue_d[level & 1];
+        a.q_out_o = ws.queue_o[(level + 1) & 1];
+        a.q_out_d = ws.queue_d[(level + 1) & 1];
+        int grid = full_grid;
+        if (level == 0) {
+            int need = (int)((a.n_slots + BLOCK - 1) / BLOCK);
+            if (need < grid) grid = need;
+        }
+        const bool primary = level == 0, count = fp.count_tests != 0;
+        if (scene.accel == 1) {
+            if (fp.stack_depth <= 32) launch_bounce_sel<1, 32>(a, primary, count, grid, stream);
+            else launch_bounce_sel<1, 64>(a, primary, count, grid, stream);
+        } else {
+            launch_bounce_sel<0, 1>(a, primary, count, grid, stream);
+        }
+        launches++;
+        if (int rc = stamp()) return rc;
+    }
+    ResolveArgs r;
+    r.sc = scene;
+    r.n_pixels = n_pixels;
+    r.max_depth = fp.max_depth;
+    r.records = ws.records;
+    r.rgb8 = (uint8_t *)d_rgb8;
+    r.hit_id = (int32_t *)d_hit_id;
+    r.rgb32 = (float *)d_rgb32;
+    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, r);
+    launches++;
+    if (int rc = stamp()) return rc;
+    RT_HIP_CHECK(hipGetLastError(), err);
+    if (n_launches) *n_launches = launches;
+    return RT_OK;
+}
+
+int trace_deinterleave(const void *src, void *dst, int W, int H, int band_rows, int n_parts, int rows_per_part, int bpp,
+                       hipStream_t stream)
+{
+    size_t total = (size_t)W * H * bpp;
+    if (total == 0) return RT_OK;
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint8_t *)src,
+                       (uint8_t *)dst, W, H, band_rows, n_parts, rows_per_part, bpp);
+    return hipGetLastError() == hipSuccess ? RT_OK : RT_E_DEVICE;
+}
