@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X trace path.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow + reflect, counted as the reference would
+cast them) on the Sponza-class workload at 1920x1080 with hard shadows and 4 reflection
+bounces, on N GPUs of one node (frame tile-partitioned, scene replicated, RGB8 slices
+gathered with RCCL).  One "step" = one full frame: every bounce level's trace kernel, the
+resolve/quantise kernel and, for N > 1, the gather + de-interleave.  The scene (triangles,
+LBVH) is resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+# algorithmic flops per intersection test (Moller-Trumbore main.cpp:109-129; slab test;
+# sphere main.cpp:56-68; plane main.cpp:84-92)
+FLOP_TRI, FLOP_BOX, FLOP_ANALYTIC = 46, 20, 17
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "cube", "soup"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=-1)
+    ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--leaf-max", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, threads):
+    """Time the CPU restatement of the reference (oracle/, OpenMP over rows, its own BVH) on a
+    bounded sample of the same workload: one full frame."""
+    from oracle import oracle as O   # checker used only as the reported CPU baseline
+    sc = O.scene_from_workload(wl, bvh=True)
+    cam = O.camera_from(wl.camera)
+    step = 1
+    t0 = time.perf_counter()
+    r = sc.render(wl.W, wl.H, max_depth=wl.max_depth, cam=cam, use_bvh=True, threads=threads, x_step=step, y_step=step,
+                  want=())
+    dt = time.perf_counter() - t0
+    rays = r["counts"]["primary"] + r["counts"]["shadow"] + r["counts"]["reflect"]
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": "one full %dx%d frame (%d rays) through the CPU restatement with its median-split BVH, "
+                     "OpenMP over rows" % (wl.W, wl.H, rays), "seconds": dt}
+    # The reference's own algorithm is a linear scan over all primitives: time it single-threaded
+    # on a sparse lattice so the number stays bounded.
+    lat = 96
+    t0 = time.perf_counter()
+    r = sc.render(wl.W, wl.H, max_depth=wl.max_depth, cam=cam, use_bvh=False, threads=1, x_step=lat, y_step=lat, want=())
+    dt = time.perf_counter() - t0
+    rays = r["counts"]["primary"] + r["counts"]["shadow"] + r["counts"]["reflect"]
+    out["linear_scan_1core"] = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1,
+                                "sample": "every %dth row and column (%d rays), brute-force scan as main.cpp:149-156" % (lat, rays),
+                                "seconds": dt}
+    return out
+
+
+def main():
+    a = parse()
+    import torch
+    import raytracer_amd as rt
+    from raytracer_amd import workloads
+    from raytracer_amd.dist import PartitionedRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % a.gpus)
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    kw = {}
+    if a.width: kw["W"] = a.width
+    if a.height: kw["H"] = a.height
+    if a.depth >= 0: kw["max_depth"] = a.depth
+    wl = workloads.by_name(a.workload, **kw)
+
+    ctx = rt.Context(local_rank)
+    if a.leaf_max:
+        ctx.set_option(rt.OPT_LEAF_MAX, a.leaf_max)
+    wl.load(ctx)
+    pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        pr.render()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pr.render()
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()   # last frame of this rank: ray counts + device-event kernel times
+
+    rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
+    vec = torch.tensor([dt, float(rays_local), float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"]),
+                        st["ms_trace"], st["ms_frame"]], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = vec.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vec.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+        rays = float(sm[1]); rp, rs, rr = float(sm[2]), float(sm[3]), float(sm[4])
+        ms_trace, ms_frame = float(mx[5]), float(mx[6])
+    else:
+        rays = float(rays_local); rp, rs, rr = float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"])
+        ms_trace, ms_frame = st["ms_trace"], st["ms_frame"]
+
+    # ---- roofline of the dominant kernel (k_bounce, all levels of one frame), rank 0's share:
+    # algorithmic flops from a counting pass outside the timed region, duration from the
+    # device events the library records around those launches on the launch stream.
+    ctx.set_option(rt.OPT_COUNT_TESTS, 1)
+    pr.render()
+    cst = ctx.stats()
+    ctx.set_option(rt.OPT_COUNT_TESTS, 0)
+    flops = cst["box_tests"] * FLOP_BOX + cst["tri_tests"] * FLOP_TRI + cst["analytic_tests"] * FLOP_ANALYTIC
+    achieved = flops / (st["ms_trace"] * 1e-3) / 1e12 if st["ms_trace"] > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a.workload if world == 1 else "", {}).get("bytes_per_frame")
+        except Exception:
+            traffic = None
+    compulsory = wl.W * wl.H * 3 + wl.n_tris * (48 + 16) + st["bvh_nodes"] * 64
+    roofline = {
+        "bound": "valu_fp32", "kernel": "k_bounce (all %d levels of one frame)" % (wl.max_depth + 1),
+        "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+        "traffic": traffic,
+        "flops_per_frame": flops, "box_tests": cst["box_tests"], "tri_tests": cst["tri_tests"],
+        "analytic_tests": cst["analytic_tests"], "kernel_ms_per_frame": st["ms_trace"],
+        "hbm": {"compulsory_bytes_per_frame": compulsory,
+                "achieved_GBs": compulsory / (st["ms_frame"] * 1e-3) / 1e9 if st["ms_frame"] > 0 else 0.0,
+                "peak_GBs": PEAK_HBM_GBS},
+    }
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflect)", "value": rays * a.steps / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name, "triangles": wl.n_tris, "resolution": [wl.W, wl.H], "bounces": wl.max_depth,
+                       "accel": "lbvh" if st["accel"] else "linear", "bvh_depth": st["bvh_depth"],
+                       "leaf_max": st["bvh_leaf_max"], "partition": "%d-row bands round-robin" % a.band_rows if world > 1 else "none",
+                       "rays_per_frame": {"primary": rp, "shadow": rs, "reflect": rr}},
+            "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            threads = a.cpu_threads or min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(wl, threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

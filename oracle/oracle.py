@@ -289,3 +289,23 @@ def stock_prims():
         sphere((-2.0, 5.0, -3.0), 0.1, material(color=(0.9, 0.9, 0.4)), is_light=True),
         plane((0.0, 1.0, 0.0), -4.0),
     ]
+
+
+def scene_from_workload(wl, bvh=True):
+    """Mirror a raytracer_amd.workloads.Workload (duck-typed: analytic records with
+    kind/is_light/mat/p/s, a mesh and a material table) into an oracle Scene, in the same
+    scene order: analytic primitives first, then one triangle per index triple."""
+    def m(x):
+        return material(x.reflect, x.diffuse, x.spec, tuple(x.color))
+    prims = []
+    for a in wl.analytic:
+        if a.kind == SPHERE:
+            prims.append(sphere(tuple(a.p), a.s, m(a.mat), bool(a.is_light)))
+        else:
+            prims.append(plane(tuple(a.p), a.s, m(a.mat)))
+    mesh = triangles_from_mesh(wl.verts, wl.indices, [m(x) for x in wl.mats], wl.tri_material)
+    return Scene(prims, bvh=bvh, mesh=mesh)
+
+
+def camera_from(cam):
+    return camera(tuple(cam.origin), cam.pitch, cam.off_x, cam.off_y, cam.plane_z)
