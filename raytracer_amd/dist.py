@@ -45,7 +45,7 @@ class PartitionedRenderer:
         self.cap_rows = rows_per_part(H, band_rows, world) if world > 1 else H
         dev = device if device is not None else torch.device("cuda", ctx.device)
         self.local = torch.zeros((self.cap_rows, W, 3), dtype=torch.uint8, device=dev)
-        self.gathered = torch.empty((world, self.cap_rows, W, 3), dtype=torch.uint8, device=dev) if world > 1 else None
+        self.gathered = torch.empty((world * self.cap_rows, W, 3), dtype=torch.uint8, device=dev) if world > 1 else None
         self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
 
     def render(self):

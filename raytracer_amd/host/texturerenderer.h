@@ -1,0 +1,18 @@
+// texturerenderer.h — frame sink with the reference's three entry points
+// (Raytracer/texturerenderer.h:14-20).  Instead of uploading the frame to a GL texture
+// (texturerenderer.cpp:90-93) it keeps it and, on draw, writes it to the configured files.
+#pragma once
+
+struct color {
+    char r, g, b;   // 3-byte packed pixel, row-major, row 0 = bottom of the displayed image
+};
+
+void texturerenderer_setup();
+void texturerenderer_displaytexture(color *pixels, int w, int h);
+void texturerenderer_draw();
+
+// Headless outputs.  NULL disables.  PPM is written upright (last buffer row first) unless
+// raw_order is set, in which case rows go out in buffer order.
+void texturerenderer_set_output(const char *ppm_path, bool raw_order);
+// Optional float frame (3 floats per pixel, same layout) written as a PFM file.
+void texturerenderer_set_float_output(const char *pfm_path, const float *rgb32);

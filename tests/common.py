@@ -149,3 +149,48 @@ def compare(gpu, ref, rgb_tol=1):
         out["rgb32_max_abs"] = float(np.nanmax(np.abs(gpu["rgb32"] - ref["rgb32"]))) if n else 0.0
     out["pixels"] = int(n)
     return out
+
+
+# ------------------------------------------------------------------ golden cases
+def lcg_floats(n, seed):
+    """Deterministic uniform [0,1) floats that do not depend on numpy's generators."""
+    out = np.empty(n, np.float64)
+    s = seed & 0xFFFFFFFF
+    for i in range(n):
+        s = (1664525 * s + 1013904223) & 0xFFFFFFFF
+        out[i] = s / 4294967296.0
+    return out
+
+
+def soup_spec(n_tris=40, seed=7):
+    """Random triangles in front of the reference camera, four materials (one a mirror), plus
+    a reflective floor plane (exercises the plane's any-t>0 self-hit rule, main.cpp:91) and
+    a sphere that contains the camera (negative-t hits, main.cpp:66-67)."""
+    r = lcg_floats(n_tris * 12, seed).reshape(n_tris, 12)
+    c = np.stack([r[:, 0] * 8 - 4, r[:, 1] * 6 - 4, r[:, 2] * 8 - 1], 1)
+    tri = c[:, None, :] + (r[:, 3:12].reshape(n_tris, 3, 3) - 0.5) * 2.5
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    idx = np.arange(n_tris * 3, dtype=np.int32)
+    mats = [(0.0, 1.0, 1.0, (1.0, 1.0, 1.0)), (0.6, 0.7, 0.5, (0.9, 0.3, 0.2)), (1.0, 0.0, 1.0, (1.0, 1.0, 1.0)),
+            (0.3, 1.0, 0.0, (0.2, 0.8, 0.4))]
+    tm = (np.arange(n_tris) % 4).astype(np.int32)
+    a = [sphere((2.0, 5.0, 1.0), 0.1, (0.0, 1.0, 1.0, (0.7, 0.7, 0.9)), True),
+         plane((0.0, 1.0, 0.0), -4.0, (0.4, 1.0, 1.0, (0.8, 0.8, 0.8))),
+         sphere((-2.0, 5.0, -3.0), 0.1, (0.0, 1.0, 1.0, (0.9, 0.9, 0.4)), True),
+         sphere((0.0, 0.0, 3.0), 9.0, (0.2, 0.5, 1.0, (0.3, 0.3, 0.5)))]
+    return SceneSpec(a, verts, idx, mats=mats, tri_material=tm)
+
+
+def golden_cases():
+    """name -> (spec, W, H, bounces, camera).  Small enough for the unmodified reference
+    (brute force, scalar) to render in seconds."""
+    cam160 = rt.Camera(pitch=0.05)
+    cam200 = rt.Camera(pitch=0.04)
+    return {
+        "stock_160": (stock_spec(), 160, 120, 3, cam160),
+        "cube_hidden_160": (cube_spec(mirror=True), 160, 120, 3, cam160),
+        "cube_d1_200": (cube_spec(mirror=False), 200, 150, 1, cam200),
+        "cube_refl_d4_200": (cube_spec(mirror=False, mesh_reflect=0.5), 200, 150, 4, cam200),
+        "soup_d3_160": (soup_spec(), 160, 120, 3, cam160),
+        "soup_d8_160": (soup_spec(n_tris=24, seed=99), 160, 120, 8, rt.Camera(origin=(0.5, -1.0, -6.0), pitch=0.05, off_x=-4.2, off_y=-3.5, plane_z=0.25)),
+    }

@@ -1,0 +1,123 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared
+symbol, the C++ host's OBJ loader reproduces the reference parser's outputs, the band
+partition covers the frame exactly once, and the synthetic scenes are deterministic."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, ROOT, rt, scenes
+
+HOST_BIN = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+
+
+def test_library_exports_every_declared_symbol():
+    L = rt.load_library()
+    header = open(os.path.join(ROOT, "include", "rt_shim.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", header))
+    assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.rt_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    # sizes the C side assumes (include/rt_shim.h); a mismatch would corrupt every call
+    assert ctypes.sizeof(rt.Material) == 24
+    assert ctypes.sizeof(rt.Analytic) == 8 + 24 + 12 + 4
+    assert ctypes.sizeof(rt.Camera) == 28
+    assert ctypes.sizeof(rt.RowSet) == 16
+    assert ctypes.sizeof(rt.Stats) == 96   # 6 x u64 + 3 x f32 + 7 x i32 + f32, padded to 8
+
+
+def test_null_context_is_rejected_without_touching_a_gpu():
+    L = rt.load_library()
+    assert L.rt_set_option(None, rt.OPT_ACCEL, 0) == -1
+    assert b"null" in L.rt_last_error()
+    assert L.rt_render_frame(None, 8, 8, 0, 8, 1, None, None, None) == -1
+
+
+def _dump(path):
+    out = subprocess.run([HOST_BIN, "--dump-obj", path], check=True, capture_output=True, text=True).stdout.splitlines()
+    head = dict(zip(out[0].split()[0::2], map(int, out[0].split()[1::2])))
+    v = np.array([[float(x) for x in l.split()[1:]] for l in out if l.startswith("v ")], np.float32).reshape(-1)
+    i = [int(l.split()[1]) for l in out if l.startswith("i ")]
+    return head, v, i
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_obj_loader_matches_reference_parser_outputs():
+    cases = json.load(open(os.path.join(GOLDEN, "obj_cases.json")))
+    with tempfile.TemporaryDirectory() as td:
+        for name, c in cases.items():
+            if c["text"] is None:
+                continue
+            p = os.path.join(td, "c.obj")
+            with open(p, "wb") as f:
+                f.write(c["text"].encode())
+            head, v, i = _dump(p)
+            assert head["malformed"] == 0, name
+            assert np.array_equal(v, np.array(c["verts"], np.float32)), name
+            assert i == c["indices"], name
+        head, v, i = _dump(os.path.join(td, "missing.obj"))      # silent on a missing file (objloader.cpp:22,104)
+        assert head["verts"] == 0 and head["indices"] == 0
+        # a face with an empty corner is what the reference asserts on (objloader.cpp:83)
+        p = os.path.join(td, "bad.obj")
+        open(p, "w").write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1  2 3\n")
+        head, v, i = _dump(p)
+        assert head["malformed"] == 1
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_loader_on_written_cube_equals_reference_cube():
+    ref = json.load(open(os.path.join(GOLDEN, "obj_cases.json")))["__reference_cube__"]
+    v, q = scenes.cube_quads()
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "cube.obj")
+        scenes.write_obj(p, v, q)
+        head, hv, hi = _dump(p)
+    assert np.array_equal(hv, np.array(ref["verts"], np.float32))
+    assert hi == ref["indices"]
+    cv, ci = scenes.cube_mesh()
+    assert list(ci) == ref["indices"] and np.array_equal(cv.reshape(-1), np.array(ref["verts"], np.float32))
+
+
+@pytest.mark.parametrize("H,band,parts", [(1080, 16, 8), (1080, 16, 3), (600, 16, 4), (37, 8, 2), (5, 16, 4), (64, 1, 7)])
+def test_band_partition_covers_every_row_once(H, band, parts):
+    from raytracer_amd.dist import local_rows, deinterleave_numpy
+    seen = np.zeros(H, int)
+    cap = rt.rows_per_part(H, band, parts)
+    gathered = np.full((parts, cap, 3), -1, np.int64)
+    for p in range(parts):
+        ys = local_rows(H, band, p, parts)
+        rs = rt.band_rowset(H, band, p, parts)
+        assert len(ys) == rs.n_rows <= cap
+        assert (ys < H).all() and (np.diff(ys) > 0).all()
+        seen[ys] += 1
+        gathered[p, : len(ys), :] = ys[:, None]
+    assert (seen == 1).all()
+    full = deinterleave_numpy(gathered, H, band)
+    assert np.array_equal(full[:, 0], np.arange(H))
+
+
+def test_scenes_are_deterministic_and_sized():
+    v1, i1, m1 = scenes.atrium_mesh(detail=0.05)
+    v2, i2, m2 = scenes.atrium_mesh(detail=0.05)
+    assert v1.dtype == np.float32 and i1.dtype == np.int32
+    assert np.array_equal(v1, v2) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
+    assert i1.max() < len(v1) and i1.min() >= 0 and len(i1) % 3 == 0 and len(m1) == len(i1) // 3
+    assert m1.max() < scenes.ATRIUM_MATERIALS
+    from raytracer_amd import workloads
+    wl = workloads.sponza()
+    assert 255_000 <= wl.n_tris <= 270_000
+    vi, ii, mi = scenes.instance_grid(v1, i1, m1, 2, 3, 15.0, 23.0)
+    assert len(ii) == 6 * len(i1) and ii.max() == len(vi) - 1
+
+
+def test_camera_pitch_at_800_is_the_reference_literal():
+    assert np.float32(rt.camera_for_width(800).pitch).view(np.uint32) == np.float32(0.01).view(np.uint32)

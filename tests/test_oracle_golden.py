@@ -1,0 +1,142 @@
+"""The CPU oracle against the reference's own outputs: committed fixtures generated from the
+unmodified reference build (tests/golden/make_golden.py) and, where oracle/_ref is present,
+the reference object code itself.  Bar: bit-exact (float results compared as uint32)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, O, golden_cases, ocam, stock_spec, to_oracle
+
+CANONICAL_PPM_MD5 = "5f2bfd8200db66b34ffbd553afba6cf4"   # unmodified reference, -O0, 800x600 depth 3
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_stock_frame_fixture_is_the_canonical_frame(golden_stock):
+    img = golden_stock["rgb8"]
+    assert img.shape == (600, 800, 3)
+    assert hashlib.md5(b"P6\n800 600\n255\n" + img.tobytes()).hexdigest() == CANONICAL_PPM_MD5
+    assert str(golden_stock["ppm_md5"]) == CANONICAL_PPM_MD5
+
+
+def test_oracle_reproduces_stock_frame_byte_for_byte(golden_stock):
+    r = to_oracle(stock_spec()).render(800, 600, max_depth=3)
+    assert np.array_equal(r["rgb8"], golden_stock["rgb8"])
+    # ray counts of the reference on this frame (counter-instrumented copy)
+    assert (r["counts"]["primary"], r["counts"]["shadow"], r["counts"]["reflect"]) == (480000, 1112248, 236124)
+
+
+@pytest.mark.parametrize("name", sorted(golden_cases().keys()))
+def test_oracle_matches_reference_outputs(name, golden_scenes):
+    spec, W, H, bounces, cam = golden_cases()[name]
+    r = to_oracle(spec).render(W, H, max_depth=bounces, cam=ocam(cam))
+    assert np.array_equal(r["hit_id"], golden_scenes[name + "/hit_id"])
+    assert np.array_equal(bits(r["hit_t"]), bits(golden_scenes[name + "/hit_t"]))
+    assert np.array_equal(bits(r["rgb32"]), bits(golden_scenes[name + "/rgb32"]))
+    assert np.array_equal(r["rgb8"], golden_scenes[name + "/rgb8"])
+
+
+@pytest.mark.parametrize("name", sorted(golden_cases().keys()))
+def test_oracle_bvh_equals_linear_scan(name, golden_scenes):
+    spec, W, H, bounces, cam = golden_cases()[name]
+    if spec.n_tris < 2:
+        pytest.skip("no mesh")
+    r = to_oracle(spec, bvh=True).render(W, H, max_depth=bounces, cam=ocam(cam), use_bvh=True, threads=4)
+    assert np.array_equal(r["hit_id"], golden_scenes[name + "/hit_id"])
+    assert np.array_equal(bits(r["rgb32"]), bits(golden_scenes[name + "/rgb32"]))
+
+
+def test_oracle_threads_and_lattice_do_not_change_pixels(golden_scenes):
+    spec, W, H, bounces, cam = golden_cases()["soup_d3_160"]
+    sc = to_oracle(spec)
+    a = sc.render(W, H, max_depth=bounces, cam=ocam(cam), threads=1)
+    b = sc.render(W, H, max_depth=bounces, cam=ocam(cam), threads=4)
+    assert np.array_equal(bits(a["rgb32"]), bits(b["rgb32"])) and a["counts"] == b["counts"]
+    c = sc.render(W, H, max_depth=bounces, cam=ocam(cam), x_step=4, y_step=3)
+    assert np.array_equal(bits(c["rgb32"][::3, ::4]), bits(a["rgb32"][::3, ::4]))
+    part = sc.render(W, H, y0=37, y1=90, max_depth=bounces, cam=ocam(cam))
+    assert np.array_equal(bits(part["rgb32"]), bits(a["rgb32"][37:90]))
+
+
+def test_quantise_truncates_like_the_debug_build():
+    q = O.quantise
+    assert q(1.0) == 255 and q(2.5) == 255 and q(0.999) == 254 and q(-0.3) == 0 and q(0.0) == 0
+    assert q(0.5) == 127 and q(float("nan")) == 0 and q(1.0 / 255.0) == 1 and q(0.00392) == 0
+
+
+def test_intersector_quirks():
+    import ctypes as C
+    f3 = lambda v: (C.c_float * 3)(*v)
+    t = C.c_float()
+    L = O.lib()
+    # sphere around the ray origin with its centre ahead: a hit with NEGATIVE t (main.cpp:66-67)
+    s = O.sphere((0, 0, 1), 5.0)
+    assert L.rto_sphere_raycast(C.byref(s), f3((0, 0, 0)), f3((0, 0, 1)), C.cast(C.byref(t), C.POINTER(C.c_float))) == 1
+    assert t.value == -4.0
+    # centre behind the origin: miss even though the origin is inside (main.cpp:60-61)
+    s = O.sphere((0, 0, -1), 5.0)
+    assert L.rto_sphere_raycast(C.byref(s), f3((0, 0, 0)), f3((0, 0, 1)), C.cast(C.byref(t), C.POINTER(C.c_float))) == 0
+    # plane: parallel ray misses, t must be > 0 (main.cpp:87-91)
+    p = O.plane((0, 1, 0), -4.0)
+    assert L.rto_plane_raycast(C.byref(p), f3((0, 0, 0)), f3((1, 0, 0)), C.cast(C.byref(t), C.POINTER(C.c_float))) == 0
+    assert L.rto_plane_raycast(C.byref(p), f3((0, 0, 0)), f3((0, 1, 0)), C.cast(C.byref(t), C.POINTER(C.c_float))) == 0
+    assert L.rto_plane_raycast(C.byref(p), f3((0, 0, 0)), f3((0, -1, 0)), C.cast(C.byref(t), C.POINTER(C.c_float))) == 1
+    assert t.value == 4.0
+    # triangle: two-sided, |det| < 1e-4 rejected, t must exceed 1e-4 (main.cpp:113, 128)
+    tr = O.triangle((0, 0, 1), (1, 0, 1), (0, 1, 1))
+    pt = C.cast(C.byref(t), C.POINTER(C.c_float))
+    assert L.rto_tri_raycast(C.byref(tr), f3((0.2, 0.2, 0)), f3((0, 0, 1)), pt) == 1 and t.value == 1.0
+    assert L.rto_tri_raycast(C.byref(tr), f3((0.2, 0.2, 2)), f3((0, 0, -1)), pt) == 1 and t.value == 1.0
+    assert L.rto_tri_raycast(C.byref(tr), f3((0.2, 0.2, 1)), f3((0, 0, 1)), pt) == 0          # t = 0
+    assert L.rto_tri_raycast(C.byref(tr), f3((0.2, 0.2, 0)), f3((1, 0, 0)), pt) == 0          # parallel
+    tiny = O.triangle((0, 0, 1), (0.005, 0, 1), (0, 0.005, 1))                                # det = 2.5e-5
+    assert L.rto_tri_raycast(C.byref(tiny), f3((0.001, 0.001, 0)), f3((0, 0, 1)), pt) == 0
+
+
+def test_oracle_obj_loader_matches_reference_parser():
+    cases = json.load(open(os.path.join(GOLDEN, "obj_cases.json")))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for name, c in cases.items():
+            if c["text"] is None:
+                continue
+            p = os.path.join(td, "c.obj")
+            with open(p, "wb") as f:
+                f.write(c["text"].encode())
+            rc, v, i = O.load_obj(p)
+            assert rc == 0, name
+            assert np.array_equal(v.reshape(-1), np.array(c["verts"], np.float32)), name
+            assert list(i) == c["indices"], name
+        rc, v, i = O.load_obj(os.path.join(td, "missing.obj"))
+        assert rc == 0 and len(v) == 0 and len(i) == 0
+        assert cases["__missing_file__"]["verts"] == [] and cases["__missing_file__"]["indices"] == []
+
+
+@pytest.mark.skipif(not O.Reference.available(), reason="oracle/_ref not built")
+def test_oracle_matches_live_reference_object_code():
+    """Same comparison against the reference's own object code, on a case not in the fixtures."""
+    from common import cube_spec
+    import raytracer_amd as rt
+    spec = cube_spec(mirror=False, mesh_reflect=0.35)
+    cam = rt.Camera(origin=(0.3, 0.5, -4.0), pitch=0.05, off_x=-3.9, off_y=-3.0, plane_z=0.5)
+    ref = O.Reference()
+    ref.clear()
+    for a in spec.analytic:
+        m = O.material(*a["mat"][:3], a["mat"][3])
+        if a["kind"] == "sphere":
+            ref.L.ref_add_sphere(O._f3(a["p"]), a["s"], ref._mat(m), int(a["is_light"]))
+        else:
+            ref.L.ref_add_plane(O._f3(a["p"]), a["s"], ref._mat(m))
+    for i0, i1, i2 in spec.indices.reshape(-1, 3):
+        ref.add_triangle(spec.verts[i0], spec.verts[i1], spec.verts[i2], O.material(*spec.mesh_mat[:3], spec.mesh_mat[3]))
+    want = ref.render(160, 120, bounces=5, cam=ocam(cam))
+    ref.clear()
+    got = to_oracle(spec).render(160, 120, max_depth=5, cam=ocam(cam))
+    assert np.array_equal(got["hit_id"], want["hit_id"])
+    assert np.array_equal(bits(got["rgb32"]), bits(want["rgb32"]))
+    assert np.array_equal(bits(got["hit_t"]), bits(want["hit_t"]))
