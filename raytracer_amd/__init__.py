@@ -12,10 +12,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")   # RT_AMD_LIB: A/B-test another build
 
 RT_SPHERE, RT_PLANE = 0, 1
-OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING = 1, 2, 3, 4
+OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING, OPT_PIPELINE = 1, 2, 3, 4, 5
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48
 

@@ -315,10 +315,19 @@ __global__ void k_refit_level(const int2 *__restrict__ children, const int *__re
 // reached and are left zeroed.
 __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
-                       const float4 *__restrict__ box_hi, BvhNode *nodes, int *live_depth)
+                       const float4 *__restrict__ box_hi, BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    // 16-bit lattice over the root box (the union of all padded leaf boxes)
+    const float4 rlo = box_lo[0], rhi = box_hi[0];
+    const float gb[3] = { rlo.x, rlo.y, rlo.z };
+    float gs[3] = { (rhi.x - rlo.x) * (1.0f / 65535.0f), (rhi.y - rlo.y) * (1.0f / 65535.0f), (rhi.z - rlo.z) * (1.0f / 65535.0f) };
+    for (int k = 0; k < 3; k++)
+        if (!(gs[k] > 0.0f)) gs[k] = 1e-30f;
+    if (i == 0) {
+        for (int k = 0; k < 3; k++) { grid->base[k] = gb[k]; grid->step[k] = gs[k]; }
+    }
     if (parent[i] >= 0) {
         // A non-root node spanning <= leaf_max triangles is referenced as a leaf by its
         // parent, or lies inside such a leaf: never traversed.  Ranges nest, so every
@@ -345,6 +354,23 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     nd.z01 = make_float4(l0.z, h0.z, l1.z, h1.z);
     nd.ch = make_int4(enc[0], enc[1], 0, 0);
     nodes[i] = nd;
+    // The same two boxes rounded OUTWARD onto the lattice: base + q*step <= lo and >= hi (computed in
+    // double so the floor/ceil are exact), 32 bytes per node instead of 64.
+    const float lo[2][3] = { { l0.x, l0.y, l0.z }, { l1.x, l1.y, l1.z } }, hi[2][3] = { { h0.x, h0.y, h0.z }, { h1.x, h1.y, h1.z } };
+    unsigned int w[6];
+    for (int c2 = 0; c2 < 2; c2++) {
+        for (int k = 0; k < 3; k++) {
+            double ql = floor(((double)lo[c2][k] - (double)gb[k]) / (double)gs[k]);
+            double qh = ceil(((double)hi[c2][k] - (double)gb[k]) / (double)gs[k]);
+            ql = fmin(fmax(ql, 0.0), 65535.0);
+            qh = fmin(fmax(qh, 0.0), 65535.0);
+            w[c2 * 3 + k] = (unsigned int)ql | ((unsigned int)qh << 16);
+        }
+    }
+    BvhNodeQ qn;
+    qn.a = make_uint4(w[0], w[1], w[2], w[3]);
+    qn.b = make_uint4(w[4], w[5], (unsigned int)enc[0], (unsigned int)enc[1]);
+    qnodes[i] = qn;
     atomicMax(live_depth, depth[i] + 1);
 }
 
@@ -397,6 +423,7 @@ int tri_setup_indexed(const float *d_verts, int n_verts, const int32_t *d_indice
 void lbvh_free(LbvhResult *r)
 {
     if (r->nodes) (void)hipFree(r->nodes);
+    if (r->qnodes) (void)hipFree(r->qnodes);
     if (r->bvh_tri) (void)hipFree(r->bvh_tri);
     *r = LbvhResult();
 }
@@ -427,7 +454,10 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, Lb
     A(bounds.alloc(6)); A(vals[0].alloc(n)); A(vals[1].alloc(n)); A(keys[0].alloc(n)); A(keys[1].alloc(n));
     A(hist.alloc((size_t)256 * n_tiles)); A(children.alloc(n)); A(range.alloc(n)); A(parent.alloc(2 * (size_t)n));
     A(depth.alloc(n)); A(scalars.alloc(2)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
+    DevBuf<QuantGrid> grid;
+    A(grid.alloc(1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
+    A(hipMalloc((void **)&out->qnodes, sizeof(BvhNodeQ) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
     if (e != hipSuccess) {
         if (err) *err = std::string("lbvh_build allocation: ") + hipGetErrorString(e);
@@ -454,6 +484,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, Lb
     }
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 2 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(out->qnodes, 0, sizeof(BvhNodeQ) * (size_t)(n - 1), stream), err);
     hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
                        parent.p);
     hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
@@ -465,12 +496,13 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, Lb
         hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n - 1, level,
                            box_lo.p, box_hi.p);
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
-                       leaf_max, box_lo.p, box_hi.p, out->nodes, scalars.p + 1);
+                       leaf_max, box_lo.p, box_hi.p, out->nodes, out->qnodes, grid.p, scalars.p + 1);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
     RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
     int live_depth = 0;
     RT_HIP_CHECK(hipMemcpyAsync(&live_depth, scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+    RT_HIP_CHECK(hipMemcpyAsync(&out->grid, grid.p, sizeof(QuantGrid), hipMemcpyDeviceToHost, stream), err);
     RT_HIP_CHECK(hipStreamSynchronize(stream), err);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);

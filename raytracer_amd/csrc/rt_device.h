@@ -1,0 +1,174 @@
+// rt_device.h — device-side arithmetic shared by the trace kernels: the reference's vec3
+// operators, intersectors and camera ray, written operation for operation as
+// Raytracer/maths.h and Raytracer/main.cpp evaluate them (no contraction, IEEE divide/sqrt).
+#pragma once
+
+#include "rt_internal.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int NODE_SENTINEL = 0x7fffffff;
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 mk(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 f3(float4 v) { return mk(v.x, v.y, v.z); }
+__device__ __forceinline__ F3 muls(F3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }            // maths.h:102
+__device__ __forceinline__ F3 add(F3 a, F3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }           // maths.h:110
+__device__ __forceinline__ F3 mulv(F3 a, F3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }          // maths.h:117
+__device__ __forceinline__ F3 sub(F3 a, F3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }           // maths.h:132
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // maths.h:140
+__device__ __forceinline__ F3 normalize(F3 a)                                                           // maths.h:158-162
+{
+    float len = sqrtf(dot(a, a));
+    return mk(a.x / len, a.y / len, a.z / len);
+}
+__device__ __forceinline__ F3 cross(F3 a, F3 b)                                                         // maths.h:165-172
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// powf(x, 20.0f) for x > 0 (main.cpp:203).  Five double multiplications carry a
+// relative error below 1e-15, so the float result is the correctly rounded power
+// except within that distance of a rounding boundary.
+__device__ __forceinline__ float pow20(float x)
+{
+    double a = (double)x;
+    double a2 = a * a, a4 = a2 * a2, a5 = a4 * a, a10 = a5 * a5;
+    return (float)(a10 * a10);
+}
+
+// ------------------------------------------------------------------ intersectors
+__device__ __forceinline__ bool sphere_raycast(const DevAnalytic &s, F3 o, F3 d, float &t)              // main.cpp:56-68
+{
+    F3 l = sub(mk(s.px, s.py, s.pz), o);
+    float distToCenter = dot(l, d);
+    if (distToCenter < 0.0f) return false;
+    float distToIntersectSq = dot(l, l) - distToCenter * distToCenter;
+    if (distToIntersectSq > s.s2) return false;
+    t = distToCenter - sqrtf(s.s2 - distToIntersectSq);
+    return true;
+}
+
+__device__ __forceinline__ bool plane_raycast(const DevAnalytic &p, F3 o, F3 d, float &t)               // main.cpp:84-92
+{
+    F3 n = mk(p.px, p.py, p.pz);
+    float ldotn = dot(n, d);
+    if (ldotn == 0.0f) return false;
+    t = (p.s - dot(n, o)) / ldotn;
+    return t > 0.0f;
+}
+
+__device__ __forceinline__ bool tri_raycast(F3 v1, F3 e1, F3 e2, F3 o, F3 d, float &t)                  // main.cpp:109-129
+{
+    F3 P = cross(d, e2);
+    float det = dot(e1, P);
+    if (det > -0.0001f && det < 0.0001f) return false;
+    float invdet = 1.0f / det;
+    F3 T = sub(o, v1);
+    float u = dot(T, P) * invdet;
+    if (u < 0.0f || u > 1.0f) return false;
+    F3 Q = cross(T, e1);
+    float v = dot(d, Q) * invdet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(e2, Q) * invdet;
+    return t > 0.0001f;
+}
+
+struct Tally { unsigned box, tri, analytic; };
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// ------------------------------------------------------------------ nearest hit (main.cpp:147-156)
+// `nearest > t` in scene order keeps the lowest id among equal distances; out of
+// order (LBVH) the same winner is selected explicitly by (t, id).
+template <bool COUNT>
+__device__ __forceinline__ void analytic_nearest(const DevScene &sc, F3 o, F3 d, float &best_t, int &best_id, Tally &tl)
+{
+    for (int i = 0; i < sc.n_analytic; i++) {
+        const DevAnalytic a = sc.analytic[i];
+        float t;
+        bool h = (a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t);
+        if (h && best_t > t) { best_t = t; best_id = i; }
+    }
+    if (COUNT) tl.analytic += (unsigned)sc.n_analytic;
+}
+
+// Slab test of one child box against the ray interval [0, tmax].
+__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, F3 o, F3 inv,
+                                     float tmax, float &tnear)
+{
+    float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// True when ANY non-light analytic primitive accepts the ray, at any distance (main.cpp:181-188).
+template <bool COUNT>
+__device__ __forceinline__ bool analytic_occluded(const DevScene &sc, F3 o, F3 d, Tally &tl)
+{
+    for (int i = 0; i < sc.n_analytic; i++) {
+        const DevAnalytic a = sc.analytic[i];
+        if (a.is_light) continue;
+        float t;
+        if (COUNT) tl.analytic++;
+        if ((a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t)) return true;
+    }
+    return false;
+}
+
+// Camera ray of one pixel (main.cpp:267-270).  Slots walk the frame in 8x8 pixel tiles so a
+// wave's 64 primary rays form a compact bundle; returns false for slots outside the frame.
+struct PixelRay { F3 o, d; int pixel; bool live; };
+
+__device__ __forceinline__ PixelRay primary_ray(const DevCamera &cam, int W, int n_rows, const rt_rowset &rows, unsigned slot)
+{
+    PixelRay r;
+    const int tiles_per_row = (W + 7) >> 3;
+    const int tile = (int)(slot >> 6), w = (int)(slot & 63u);
+    const int x = (tile % tiles_per_row) * 8 + (w & 7);
+    const int lr = (tile / tiles_per_row) * 8 + (w >> 3);
+    r.live = x < W && lr < n_rows;
+    r.pixel = lr * W + x;
+    const int y = (rows.first_band + (lr / rows.band_rows) * rows.band_stride) * rows.band_rows + lr % rows.band_rows;
+    r.o = mk(cam.ox, cam.oy, cam.oz);                                        // main.cpp:267
+    float offsetX = (float)x * cam.pitch + cam.off_x;                        // main.cpp:268
+    float offsetY = (float)y * cam.pitch + cam.off_y;                        // main.cpp:269
+    r.d = normalize(sub(mk(offsetX, offsetY, cam.plane_z), r.o));            // main.cpp:270
+    return r;
+}
+
+// Surface data of a hit primitive: normal (main.cpp:70-73, 94-97, 131-134) and material.
+struct Surface { F3 N, Mc; float kr, kd, ks; bool emissive; };
+
+__device__ __forceinline__ Surface surface_at(const DevScene &sc, int id, F3 pos)
+{
+    Surface s;
+    if (id < sc.n_analytic) {
+        const DevAnalytic a = sc.analytic[id];
+        s.N = (a.kind == RT_SPHERE) ? normalize(sub(pos, mk(a.px, a.py, a.pz))) : mk(a.px, a.py, a.pz);
+        s.Mc = mk(a.cr, a.cg, a.cb);
+        s.kr = a.reflect; s.kd = a.diffuse; s.ks = a.spec;
+        s.emissive = a.is_light != 0;
+    } else {
+        float4 tn = sc.tri_n[id - sc.n_analytic];
+        s.N = f3(tn);
+        const DevMaterial m = sc.mats[__float_as_int(tn.w)];
+        s.Mc = mk(m.cr, m.cg, m.cb);
+        s.kr = m.reflect; s.kd = m.diffuse; s.ks = m.spec;
+        s.emissive = false;
+    }
+    return s;
+}
+
+}  // namespace

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,17 @@ struct BvhNode {
     int4 ch;      // child0, child1, unused, unused
 };
 
+// The same node with its boxes rounded outward onto a 16-bit lattice over the root box, 32 B:
+// world = base + q * step per axis (QuantGrid).  Half the bytes per traversal step.
+struct BvhNodeQ {
+    uint4 a;      // child0 x (lo | hi << 16), child0 y, child0 z, child1 x
+    uint4 b;      // child1 y, child1 z, child0 ref, child1 ref
+};
+
+struct QuantGrid {
+    float base[3], step[3];
+};
+
 // Everything a trace kernel needs about the scene (passed by value).
 struct DevScene {
     const DevAnalytic *analytic;   // [n_analytic], scene order
@@ -49,6 +61,8 @@ struct DevScene {
     const float4 *tri_n;           // [n_tris] (N.xyz, material index as int bits)
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
+    const BvhNodeQ *qnodes;        // same tree, quantised boxes
+    QuantGrid grid;
     const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
     int32_t n_analytic, n_lights, n_tris, accel;
 };
@@ -70,6 +84,8 @@ struct FrameCounters {
 
 struct LbvhResult {
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
+    BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
+    QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
     int n_nodes = 0, depth = 0, leaf_max = 0;
     float ms_build = 0.f;
@@ -93,6 +109,7 @@ struct FrameParams {
     int count_tests;
     int timing;
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
+    int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages
 };
 
 struct FrameWorkspace {
@@ -103,6 +120,16 @@ struct FrameWorkspace {
     FrameCounters *counters = nullptr;
     size_t pixels_cap = 0;
     int levels_cap = 0;
+    // wavefront pipeline (LBVH scenes)
+    float2 *hits = nullptr;        // [slots_cap] nearest (t, id bits) of the current level
+    unsigned int *occ = nullptr;   // [chunks_cap][slots_cap] shadow bits, 32 lights per word
+    float4 *sq_o = nullptr, *sq_d = nullptr;   // [seg_cap][slots_cap] shadow rays, one segment per light of a chunk
+    unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue
+    unsigned int *sq_counts = nullptr;         // [seg_cap][regions] shadow rays per segment and region
+    unsigned int *trace_cursors = nullptr;     // per-frame unit claim cursors, one row per k_trace launch
+    int *overflow = nullptr;       // traversal stack spill columns
+    size_t slots_cap = 0, overflow_cap = 0, cursors_cap = 0;
+    int chunks_cap = 0, seg_cap = 0;
     // staging outputs for the host-buffer entry point
     uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr;
     size_t out_cap = 0;
@@ -113,6 +140,14 @@ struct FrameWorkspace {
 int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws,
                 void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream,
                 int *n_launches, std::string *err);
+// wavefront.hip: the LBVH pipeline of one frame's bounce levels (records only; trace_frame resolves).
+int wavefront_trace_grid(int num_cus);
+size_t wavefront_overflow_ints(int num_cus);
+size_t wavefront_regions(size_t slots);
+size_t wavefront_cursor_words(int levels, int n_chunks);
+int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_hit_t,
+                    hipStream_t stream, int num_cus, const std::function<int()> &stamp, int *n_launches, std::string *err);
+int device_num_cus(std::string *err);   // trace.hip: CU count of the current device (cached), < 0 on error
 int trace_deinterleave(const void *src, void *dst, int W, int H, int band_rows, int n_parts, int rows_per_part,
                        int bpp, hipStream_t stream);
 

@@ -32,7 +32,7 @@ struct rt_ctx {
     int n_mats = 0;
     LbvhResult bvh;
     // options
-    int opt_accel = 0, opt_count = 0, opt_leaf_max = 4, opt_timing = 1;
+    int opt_accel = 0, opt_count = 0, opt_leaf_max = 4, opt_timing = 1, opt_pipeline = 0;
     DevCamera cam;
     FrameWorkspace ws;
     // last frame
@@ -89,22 +89,25 @@ void free_triangles(rt_ctx *c)
 void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
-                     ws.out_rgb8, ws.out_id, ws.out_rgb32 };
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.hits, ws.occ, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
+                     ws.sq_counts, ws.trace_cursors, ws.overflow };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
     ws = FrameWorkspace();
 }
 
-int ensure_workspace(rt_ctx *c, size_t pixels, int levels, bool host_outputs)
+int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, bool wavefront, bool host_outputs)
 {
     FrameWorkspace &ws = c->ws;
     if (!ws.counters) {
         if (hipMalloc((void **)&ws.counters, sizeof(FrameCounters)) != hipSuccess)
             return fail(RT_E_NOMEM, "hipMalloc(counters) failed");
     }
-    if (pixels > ws.pixels_cap || levels > ws.levels_cap) {
-        size_t pc = pixels > ws.pixels_cap ? pixels : ws.pixels_cap;
+    // ray queues are indexed by slot (the frame padded to whole 8x8 tiles, rounded up to whole regions)
+    const size_t qslots = wavefront_regions(slots > pixels ? slots : pixels) * 256;
+    if (qslots > ws.pixels_cap || levels > ws.levels_cap) {
+        size_t pc = qslots > ws.pixels_cap ? qslots : ws.pixels_cap;
         int lc = levels > ws.levels_cap ? levels : ws.levels_cap;
         void *old[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1] };
         for (void *p : old)
@@ -121,6 +124,49 @@ int ensure_workspace(rt_ctx *c, size_t pixels, int levels, bool host_outputs)
         if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("frame workspace: ") + hipGetErrorString(e));
         ws.pixels_cap = pc;
         ws.levels_cap = lc;
+    }
+    if (wavefront) {
+        // slot space: the frame padded to whole 8x8 tiles (>= pixels, also bounds every ray queue)
+        const int n_chunks = (c->n_lights + 31) / 32, segs = c->n_lights < 32 ? c->n_lights : 32;
+        std::string err;
+        const int cus = device_num_cus(&err);
+        if (cus <= 0) return fail(RT_E_DEVICE, err);
+        if (qslots > ws.slots_cap || n_chunks > ws.chunks_cap || segs > ws.seg_cap) {
+            void *old[] = { ws.hits, ws.occ, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1], ws.sq_counts };
+            for (void *p : old)
+                if (p) (void)hipFree(p);
+            ws.hits = nullptr; ws.occ = nullptr; ws.sq_o = ws.sq_d = nullptr;
+            ws.rq_counts[0] = ws.rq_counts[1] = ws.sq_counts = nullptr;
+            const size_t sc = qslots > ws.slots_cap ? qslots : ws.slots_cap;
+            const int cc = n_chunks > ws.chunks_cap ? n_chunks : ws.chunks_cap, gc = segs > ws.seg_cap ? segs : ws.seg_cap;
+            const size_t regions = wavefront_regions(sc);
+            ws.slots_cap = 0; ws.chunks_cap = 0; ws.seg_cap = 0;
+            hipError_t e = hipMalloc((void **)&ws.hits, sizeof(float2) * sc);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.occ, sizeof(unsigned int) * sc * (size_t)(cc ? cc : 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_o, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_d, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[0], sizeof(unsigned int) * regions);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[1], sizeof(unsigned int) * regions);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_counts, sizeof(unsigned int) * regions * (size_t)(gc ? gc : 1));
+            if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("wavefront workspace: ") + hipGetErrorString(e));
+            ws.slots_cap = sc; ws.chunks_cap = cc; ws.seg_cap = gc;
+        }
+        const size_t ctr = wavefront_cursor_words(levels, n_chunks);
+        if (ctr > ws.cursors_cap) {
+            if (ws.trace_cursors) (void)hipFree(ws.trace_cursors);
+            ws.trace_cursors = nullptr; ws.cursors_cap = 0;
+            if (hipMalloc((void **)&ws.trace_cursors, sizeof(unsigned int) * ctr) != hipSuccess)
+                return fail(RT_E_NOMEM, "hipMalloc(claim cursors) failed");
+            ws.cursors_cap = ctr;
+        }
+        const size_t ovf = wavefront_overflow_ints(cus);
+        if (ovf > ws.overflow_cap) {
+            if (ws.overflow) (void)hipFree(ws.overflow);
+            ws.overflow = nullptr; ws.overflow_cap = 0;
+            if (hipMalloc((void **)&ws.overflow, sizeof(int) * ovf) != hipSuccess)
+                return fail(RT_E_NOMEM, "hipMalloc(stack overflow columns) failed");
+            ws.overflow_cap = ovf;
+        }
     }
     if (host_outputs && pixels > ws.out_cap) {
         void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32 };
@@ -188,20 +234,23 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     c->frame_valid = false;
     const size_t pixels = (size_t)W * (size_t)rows->n_rows;
     if (pixels == 0) return RT_OK;
-    if (int rc = ensure_workspace(c, pixels, max_depth + 1, host_outputs)) return rc;
     int accel = 0;
     if (int rc = ensure_accel(c, &accel)) return rc;
+    const bool wavefront = accel == 1 && c->opt_pipeline != 1;
+    const size_t slots = (size_t)((W + 7) / 8) * (size_t)((rows->n_rows + 7) / 8) * 64;
+    if (int rc = ensure_workspace(c, pixels, slots, max_depth + 1, wavefront, host_outputs)) return rc;
 
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
     sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.mats = c->d_mats;
-    sc.nodes = c->bvh.nodes; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
 
     FrameParams fp;
     fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
     fp.count_tests = c->opt_count; fp.timing = c->opt_timing;
     fp.stack_depth = accel ? c->bvh.depth : 0;
+    fp.pipeline = c->opt_pipeline;
     if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
     std::string err;
     int launches = 0;
@@ -275,6 +324,10 @@ int rt_set_option(rt_ctx *c, int option, int value)
         c->opt_leaf_max = value;
         return RT_OK;
     case RT_OPT_TIMING: c->opt_timing = value ? 1 : 0; return RT_OK;
+    case RT_OPT_PIPELINE:
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
+        c->opt_pipeline = value;
+        return RT_OK;
     default: return fail(RT_E_INVALID, "unknown option");
     }
 }

@@ -20,97 +20,10 @@
 //
 // Float discipline: no contraction, IEEE divide/sqrt, operand order as in maths.h,
 // so every value except powf is bit-equal to the reference's x86 results.
-#include "rt_internal.h"
-
-#include <float.h>
+#include "rt_device.h"
 
 namespace {
 
-constexpr int BLOCK = 256;
-constexpr int NODE_SENTINEL = 0x7fffffff;
-
-struct F3 { float x, y, z; };
-
-__device__ __forceinline__ F3 mk(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ F3 f3(float4 v) { return mk(v.x, v.y, v.z); }
-__device__ __forceinline__ F3 muls(F3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }            // maths.h:102
-__device__ __forceinline__ F3 add(F3 a, F3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }           // maths.h:110
-__device__ __forceinline__ F3 mulv(F3 a, F3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }          // maths.h:117
-__device__ __forceinline__ F3 sub(F3 a, F3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }           // maths.h:132
-__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // maths.h:140
-__device__ __forceinline__ F3 normalize(F3 a)                                                           // maths.h:158-162
-{
-    float len = sqrtf(dot(a, a));
-    return mk(a.x / len, a.y / len, a.z / len);
-}
-__device__ __forceinline__ F3 cross(F3 a, F3 b)                                                         // maths.h:165-172
-{
-    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-
-// powf(x, 20.0f) for x > 0 (main.cpp:203).  Five double multiplications carry a
-// relative error below 1e-15, so the float result is the correctly rounded power
-// except within that distance of a rounding boundary.
-__device__ __forceinline__ float pow20(float x)
-{
-    double a = (double)x;
-    double a2 = a * a, a4 = a2 * a2, a5 = a4 * a, a10 = a5 * a5;
-    return (float)(a10 * a10);
-}
-
-// ------------------------------------------------------------------ intersectors
-__device__ __forceinline__ bool sphere_raycast(const DevAnalytic &s, F3 o, F3 d, float &t)              // main.cpp:56-68
-{
-    F3 l = sub(mk(s.px, s.py, s.pz), o);
-    float distToCenter = dot(l, d);
-    if (distToCenter < 0.0f) return false;
-    float distToIntersectSq = dot(l, l) - distToCenter * distToCenter;
-    if (distToIntersectSq > s.s2) return false;
-    t = distToCenter - sqrtf(s.s2 - distToIntersectSq);
-    return true;
-}
-
-__device__ __forceinline__ bool plane_raycast(const DevAnalytic &p, F3 o, F3 d, float &t)               // main.cpp:84-92
-{
-    F3 n = mk(p.px, p.py, p.pz);
-    float ldotn = dot(n, d);
-    if (ldotn == 0.0f) return false;
-    t = (p.s - dot(n, o)) / ldotn;
-    return t > 0.0f;
-}
-
-__device__ __forceinline__ bool tri_raycast(F3 v1, F3 e1, F3 e2, F3 o, F3 d, float &t)                  // main.cpp:109-129
-{
-    F3 P = cross(d, e2);
-    float det = dot(e1, P);
-    if (det > -0.0001f && det < 0.0001f) return false;
-    float invdet = 1.0f / det;
-    F3 T = sub(o, v1);
-    float u = dot(T, P) * invdet;
-    if (u < 0.0f || u > 1.0f) return false;
-    F3 Q = cross(T, e1);
-    float v = dot(d, Q) * invdet;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    t = dot(e2, Q) * invdet;
-    return t > 0.0001f;
-}
-
-struct Tally { unsigned box, tri, analytic; };
-
-// ------------------------------------------------------------------ nearest hit (main.cpp:147-156)
-// `nearest > t` in scene order keeps the lowest id among equal distances; out of
-// order (LBVH) the same winner is selected explicitly by (t, id).
-template <bool COUNT>
-__device__ __forceinline__ void analytic_nearest(const DevScene &sc, F3 o, F3 d, float &best_t, int &best_id, Tally &tl)
-{
-    for (int i = 0; i < sc.n_analytic; i++) {
-        const DevAnalytic a = sc.analytic[i];
-        float t;
-        bool h = (a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t);
-        if (h && best_t > t) { best_t = t; best_id = i; }
-    }
-    if (COUNT) tl.analytic += (unsigned)sc.n_analytic;
-}
 
 template <bool COUNT>
 __device__ __forceinline__ void brute_nearest(const DevScene &sc, F3 o, F3 d, float &best_t, int &best_id, Tally &tl)
@@ -121,19 +34,6 @@ __device__ __forceinline__ void brute_nearest(const DevScene &sc, F3 o, F3 d, fl
         if (tri_raycast(v1, e1, e2, o, d, t) && best_t > t) { best_t = t; best_id = sc.n_analytic + k; }
     }
     if (COUNT) tl.tri += (unsigned)sc.n_tris;
-}
-
-// Slab test of one child box against the ray interval [0, tmax].
-__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, F3 o, F3 inv,
-                                     float tmax, float &tnear)
-{
-    float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-    float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-    float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    tnear = tn;
-    return tn <= tf;
 }
 
 // stack: this lane's column of the block's LDS stack, element k at stack[k*BLOCK].
@@ -183,19 +83,6 @@ __device__ __forceinline__ void bvh_nearest(const DevScene &sc, F3 o, F3 d, bool
 
 // ------------------------------------------------------------------ shadow query (main.cpp:181-188)
 // True when ANY non-light primitive's Raycast accepts the ray, at any distance.
-template <bool COUNT>
-__device__ __forceinline__ bool analytic_occluded(const DevScene &sc, F3 o, F3 d, Tally &tl)
-{
-    for (int i = 0; i < sc.n_analytic; i++) {
-        const DevAnalytic a = sc.analytic[i];
-        if (a.is_light) continue;
-        float t;
-        if (COUNT) tl.analytic++;
-        if ((a.kind == RT_SPHERE) ? sphere_raycast(a, o, d, t) : plane_raycast(a, o, d, t)) return true;
-    }
-    return false;
-}
-
 template <bool COUNT>
 __device__ __forceinline__ bool brute_occluded(const DevScene &sc, F3 o, F3 d, Tally &tl)
 {
@@ -264,11 +151,6 @@ struct BounceArgs {
     FrameCounters *counters;
     int stack_cap;
 };
-
-__device__ __forceinline__ unsigned long long lanemask_lt()
-{
-    return (1ull << (threadIdx.x & 63)) - 1ull;
-}
 
 template <int ACCEL, bool PRIMARY, bool COUNT, int STACK>
 __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
@@ -520,15 +402,12 @@ void launch_bounce_sel(const BounceArgs &a, bool primary, bool count, int grid, 
     }
 }
 
-int g_num_cus = 0;
-
 }  // namespace
 
-int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
-                void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int *n_launches, std::string *err)
+int g_num_cus = 0;
+
+int device_num_cus(std::string *err)
 {
-    const int n_rows = fp.rows.n_rows;
-    const int n_pixels = fp.W * n_rows;
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -536,6 +415,15 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
         RT_HIP_CHECK(hipGetDeviceProperties(&prop, dev), err);
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    return g_num_cus;
+}
+
+int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
+                void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int *n_launches, std::string *err)
+{
+    const int n_rows = fp.rows.n_rows;
+    const int n_pixels = fp.W * n_rows;
+    if (device_num_cus(err) <= 0) return RT_E_DEVICE;
     RT_HIP_CHECK(hipMemsetAsync(ws.counters, 0, sizeof(FrameCounters), stream), err);
 
     BounceArgs a;
@@ -567,7 +455,12 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     int launches = 0;
     const int full_grid = g_num_cus * 8;
     if (int rc = stamp()) return rc;
-    for (int level = 0; level <= fp.max_depth; level++) {
+    const bool wavefront = scene.accel == 1 && fp.pipeline != 1;
+    if (wavefront) {
+        std::function<int()> st = stamp;
+        if (int rc = wavefront_frame(scene, cam, fp, ws, d_hit_t, stream, g_num_cus, st, &launches, err)) return rc;
+    }
+    for (int level = 0; level <= fp.max_depth && !wavefront; level++) {
         a.level = level;
         a.q_in_o = ws.queue_o[level & 1];
         a.q_in_d = ws.queue_d[level & 1];

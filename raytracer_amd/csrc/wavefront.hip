@@ -1,0 +1,587 @@
+// wavefront.hip — the LBVH trace pipeline: traversal separated from shading.
+//
+// The fused kernel in trace.hip keeps a whole ray's life in one thread; on LBVH scenes
+// its wave64 lanes spend most of their time masked off (rays end at different times,
+// node and leaf work serialise).  Here each bounce level of the reference's recursion
+// (Raytracer/main.cpp:144-217) is four wave-uniform stages over flat queues:
+//
+//   k_trace<closest>   nearest primitive per ray (main.cpp:147-156)        -> hits[slot]
+//   k_shadow_gen       per light: L, shadow-ray origin, analytic occluders
+//                      (main.cpp:178-188); survivors go to a per-light queue
+//   k_trace<any-hit>   any triangle accepting the shadow ray at any distance -> occ bits
+//   k_shade            local colour in the reference's accumulation order
+//                      (main.cpp:166-205), 16-byte record, reflection ray to the next
+//                      level's queue (main.cpp:208-211)
+//
+// Queues are REGIONED: slot space is cut into regions of 256 slots; the block that
+// processes input region r writes its surviving rays densely at the start of output
+// region r and stores the count.  Compaction is therefore block-local (ballot +
+// popcount + a 4-entry LDS prefix) and needs no global atomic; a same-address atomic
+// retires only ~90 per microsecond on this chip, which would otherwise cap the frame.
+//
+// k_trace is the hot kernel.  Waves are persistent and every LANE owns a ray: a lane
+// whose ray has finished goes idle and, once enough lanes of the wave are idle, they are
+// refilled from the wave's local range of rays; the wave claims a new 64-ray unit (one
+// atomic on a cursor sharded 8 ways, with stealing) only when that range is empty.
+// Lanes are either at an inner node or inside a leaf; each iteration the wave runs the
+// one step that more of its lanes are waiting for (ballot + popcount vote), so only one
+// body executes per iteration and at least half of the busy lanes advance.
+// The per-lane traversal stack lives in LDS (16 entries, column-per-lane: conflict-free)
+// and overflows to a global column for the rare deeper path.
+#include "rt_device.h"
+
+#include <stdlib.h>
+
+namespace {
+
+#ifndef WF_STACK
+#define WF_STACK 16
+#endif
+constexpr int WF_LDS_STACK = WF_STACK;    // stack entries per lane held in LDS
+constexpr int WF_OVF = 56;                // further entries per lane in global memory
+constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsigned)node < SENT_U" == inner node
+#ifndef WF_REFILL_MIN
+#define WF_REFILL_MIN 16
+#endif
+#ifndef WF_VOTE
+#define WF_VOTE 1
+#endif
+constexpr int REFILL_MIN = WF_REFILL_MIN; // refill once this many lanes of a wave are idle
+constexpr int REGION = BLOCK;             // slots per queue region = one producer block iteration
+constexpr int UNIT = 64;                  // rays per claimed work unit
+constexpr int UPR = REGION / UNIT;        // units per region
+constexpr int SHARDS = 64;                // claim cursors per launch
+constexpr int CURSOR_STRIDE = 32;         // words between cursors: each on its own 128-byte line, because atomics
+                                          // to one line serialise (~90 per microsecond) wherever in the line they land
+constexpr int MAX_PROBES = 8;             // shards a wave tries (its own first) before it stops claiming
+constexpr float INV_MAX = 1e30f;          // stands in for 1/0 so that lo*inv - o*inv stays finite
+
+struct TraceArgs {
+    DevScene sc;
+    DevCamera cam;
+    int W, n_rows;
+    rt_rowset rows;
+    const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit: shadow queue (segment-major)
+    float2 *hits;                   // closest: (t, id bits) per slot
+    unsigned int *occ;              // any-hit: occ[slot] |= 1 << bit
+    const unsigned int *counts;     // [segment][region] rays per region (null at level 0: regions are full)
+    unsigned int *cursors;          // [SHARDS * CURSOR_STRIDE] unit claim cursors of this launch (zeroed per frame)
+    unsigned int n_slots;           // level 0: slot count known on the host
+    int n_segments, n_regions;
+    unsigned int seg_stride;        // queue entries between segments
+    int *overflow;                  // [WF_OVF][total_lanes]
+    unsigned int total_lanes;
+    FrameCounters *counters;
+};
+
+template <bool ANYHIT, bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
+{
+    __shared__ int s_stack[WF_LDS_STACK * BLOCK];
+    const int lane = threadIdx.x & 63;
+    int *stack = s_stack + threadIdx.x;                                   // element k at stack[k * BLOCK]
+    int *ovf = A.overflow + (size_t)blockIdx.x * BLOCK + threadIdx.x;     // element k at ovf[k * total_lanes]
+    const DevScene &sc = A.sc;
+    const unsigned long long lt = lanemask_lt();
+
+    // ---- per-lane ray state
+    int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = 0;
+    unsigned int slot = 0;
+    F3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f), oi = mk(0.f, 0.f, 0.f);
+    float best_t = FLT_MAX;
+    Tally tl = { 0u, 0u, 0u };
+
+    // ---- per-wave fetch state (uniform): local range [cur, end) of queue positions in segment `seg`
+    unsigned int cur = 0, end = 0;
+    int seg = 0;
+    // Every shard needs an owner that drains it to the end: with fewer blocks than SHARDS only
+    // gridDim.x shards are used.
+    const int n_shards = (int)min((unsigned)SHARDS, gridDim.x);
+    const int max_probes = min(MAX_PROBES, n_shards);
+    int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
+    const unsigned int n_units = (unsigned)A.n_segments * (unsigned)A.n_regions * UPR;
+    bool exhausted = n_units == 0;
+
+    auto push = [&](int v) {
+        if (sp < WF_LDS_STACK) stack[sp * BLOCK] = v;
+        else ovf[(size_t)(sp - WF_LDS_STACK) * A.total_lanes] = v;
+        sp++;
+    };
+    auto pop = [&]() {
+        sp--;
+        if (sp < WF_LDS_STACK) {
+            node = stack[sp * BLOCK];
+        } else {
+            // The rare deep entry comes back through an explicit global load: left as two plain C++
+            // loads, hipcc merges the LDS and the global branch into ONE flat_load on a generic
+            // pointer, and every pop then pays the flat path's latency and waits.
+            const int *p = ovf + (size_t)(sp - WF_LDS_STACK) * A.total_lanes;
+            int v;
+            asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+            node = v;
+        }
+        if (node == NODE_SENTINEL && !ANYHIT) A.hits[slot] = make_float2(best_t, __int_as_float(best_id));
+    };
+
+    for (;;) {
+        // ---- refill idle lanes from the local range; claim a new unit when it is empty
+        const unsigned long long idle = __ballot(node == NODE_SENTINEL);
+        if (!exhausted && idle != 0ull && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+            if (cur >= end) {
+                // units are dealt to shards round-robin (unit = k*n_shards + shard); a wave drains its own
+                // shard to the end, then steals from the next few
+                unsigned int k = 0;
+                if (lane == 0) k = atomicAdd(&A.cursors[shard * CURSOR_STRIDE], 1u);
+                k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+                const unsigned long long unit = (unsigned long long)k * (unsigned)n_shards + (unsigned)shard;
+                if (unit >= n_units) {
+                    shard = shard + 1 == n_shards ? 0 : shard + 1;
+                    if (++probes >= max_probes) exhausted = true;
+                    continue;
+                }
+                const unsigned int u = (unsigned)unit;
+                const unsigned int per_seg = (unsigned)A.n_regions * UPR;
+                seg = (int)(u / per_seg);
+                const unsigned int rem = u % per_seg, region = rem / UPR, sub = rem % UPR;
+                unsigned int cnt;
+                if (PRIMARY) {
+                    const unsigned int r0 = region * REGION;
+                    cnt = A.n_slots > r0 ? min((unsigned)REGION, A.n_slots - r0) : 0u;
+                } else {
+                    cnt = A.counts[(size_t)seg * A.n_regions + region];
+                }
+                cur = region * REGION + sub * UNIT;
+                end = region * REGION + min(sub * UNIT + UNIT, cnt);
+                if (cur >= end) continue;      // empty unit
+            }
+            const unsigned int my = cur + (unsigned)__popcll(idle & lt);
+            if (node == NODE_SENTINEL && my < end) {
+                bool live = true;
+                if (ANYHIT) {
+                    const size_t q = (size_t)seg * A.seg_stride + my;
+                    const float4 qo = A.q_o[q], qd = A.q_d[q];
+                    o = f3(qo); d = f3(qd);
+                    slot = (unsigned)__float_as_int(qo.w);
+                    bit = __float_as_int(qd.w);
+                } else if (PRIMARY) {
+                    const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, my);
+                    o = pr.o; d = pr.d; live = pr.live;
+                    slot = my;
+                } else {
+                    const float4 qo = A.q_o[my], qd = A.q_d[my];
+                    o = f3(qo); d = f3(qd);
+                    slot = my;
+                }
+                if (live) {
+                    best_t = FLT_MAX; best_id = -1;
+                    if (!ANYHIT) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+                    // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf
+                    inv = mk(fminf(fmaxf(1.0f / d.x, -INV_MAX), INV_MAX), fminf(fmaxf(1.0f / d.y, -INV_MAX), INV_MAX),
+                             fminf(fmaxf(1.0f / d.z, -INV_MAX), INV_MAX));
+                    // lattice plane q maps to t = q*(step*inv) + (base - o)*inv
+                    oi = mk((sc.grid.base[0] - o.x) * inv.x, (sc.grid.base[1] - o.y) * inv.y, (sc.grid.base[2] - o.z) * inv.z);
+                    inv = mk(sc.grid.step[0] * inv.x, sc.grid.step[1] * inv.y, sc.grid.step[2] * inv.z);
+                    stack[0] = NODE_SENTINEL;
+                    sp = 1;
+                    tri_left = 0;
+                    node = 0;
+                }
+            }
+            cur = min(end, cur + (unsigned)__popcll(idle));
+        }
+
+        const unsigned long long m_node = __ballot((unsigned)node < SENT_U);
+        const unsigned long long m_leaf = __ballot(node < 0);
+        if ((m_node | m_leaf) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        const bool do_node = WF_VOTE ? (__popcll(m_node) >= __popcll(m_leaf)) : (m_node != 0ull);
+        const bool do_leaf = WF_VOTE ? !do_node : (m_leaf != 0ull);
+        if (do_node) {
+            // ---- inner-node step: both children's boxes from one 64-byte node
+            if ((unsigned)node < SENT_U) {
+                const BvhNodeQ *np = sc.qnodes + node;
+                const uint4 qa = np->a, qb = np->b;
+                const int2 ch = make_int2((int)qb.z, (int)qb.w);
+                const float tmax = ANYHIT ? FLT_MAX : best_t;
+                // one fma per box plane; the lattice boxes contain the padded float boxes
+                float a, b;
+                a = fmaf((float)(qa.x & 0xffffu), inv.x, oi.x); b = fmaf((float)(qa.x >> 16), inv.x, oi.x);
+                float n0 = fminf(a, b), f0 = fmaxf(a, b);
+                a = fmaf((float)(qa.y & 0xffffu), inv.y, oi.y); b = fmaf((float)(qa.y >> 16), inv.y, oi.y);
+                n0 = fmaxf(n0, fminf(a, b)); f0 = fminf(f0, fmaxf(a, b));
+                a = fmaf((float)(qa.z & 0xffffu), inv.z, oi.z); b = fmaf((float)(qa.z >> 16), inv.z, oi.z);
+                n0 = fmaxf(fmaxf(n0, fminf(a, b)), 0.0f); f0 = fminf(fminf(f0, fmaxf(a, b)), tmax);
+                a = fmaf((float)(qa.w & 0xffffu), inv.x, oi.x); b = fmaf((float)(qa.w >> 16), inv.x, oi.x);
+                float n1 = fminf(a, b), f1 = fmaxf(a, b);
+                a = fmaf((float)(qb.x & 0xffffu), inv.y, oi.y); b = fmaf((float)(qb.x >> 16), inv.y, oi.y);
+                n1 = fmaxf(n1, fminf(a, b)); f1 = fminf(f1, fmaxf(a, b));
+                a = fmaf((float)(qb.y & 0xffffu), inv.z, oi.z); b = fmaf((float)(qb.y >> 16), inv.z, oi.z);
+                n1 = fmaxf(fmaxf(n1, fminf(a, b)), 0.0f); f1 = fminf(fminf(f1, fmaxf(a, b)), tmax);
+                const bool h0 = n0 <= f0, h1 = n1 <= f1;
+                if (COUNT) tl.box += 2;
+                if (h0 && h1) {
+                    const bool swap = !ANYHIT && n1 < n0;
+                    push(swap ? ch.x : ch.y);
+                    node = swap ? ch.y : ch.x;
+                } else if (h0) {
+                    node = ch.x;
+                } else if (h1) {
+                    node = ch.y;
+                } else {
+                    pop();
+                }
+            }
+        }
+        if (do_leaf) {
+            // ---- leaf step: one triangle through the reference's Moller-Trumbore test
+            if (node < 0) {
+                if (tri_left == 0) {
+                    const int leaf = ~node;
+                    tri_i = leaf >> 3;
+                    tri_left = (leaf & 7) + 1;
+                }
+#ifdef WF_LEAF_LOOP
+                for (;;) {
+#endif
+                const float4 v1 = sc.bvh_tri[3 * (size_t)tri_i];
+                const F3 e1 = f3(sc.bvh_tri[3 * (size_t)tri_i + 1]), e2 = f3(sc.bvh_tri[3 * (size_t)tri_i + 2]);
+                float t;
+                const bool h = tri_raycast(f3(v1), e1, e2, o, d, t);
+                if (COUNT) tl.tri += 1;
+                tri_i++;
+                tri_left--;
+                if (ANYHIT) {
+                    if (h) {                                       // main.cpp:183-186: any hit blocks the light
+                        atomicOr(&A.occ[slot], 1u << bit);
+                        node = NODE_SENTINEL;
+                        tri_left = 0;
+                    }
+                } else if (h) {
+                    const int id = sc.n_analytic + __float_as_int(v1.w);
+                    if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
+                }
+#ifdef WF_LEAF_LOOP
+                if (node == NODE_SENTINEL || tri_left == 0) break;
+                }
+#endif
+                if (node != NODE_SENTINEL && tri_left == 0) pop();
+            }
+        }
+    }
+
+    if (COUNT) {
+        unsigned int vals[3] = { tl.box, tl.tri, tl.analytic };
+        for (int k = 0; k < 3; k++) {
+            unsigned long long v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v)
+                atomicAdd(k == 0 ? &A.counters->box_tests : k == 1 ? &A.counters->tri_tests : &A.counters->analytic_tests, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shadow-ray generation and shading
+struct ShadeArgs {
+    DevScene sc;
+    DevCamera cam;
+    int W, n_rows, n_pixels;
+    rt_rowset rows;
+    int level, max_depth;
+    unsigned int n_slots;             // level 0 slot count
+    int n_regions;
+    const unsigned int *in_counts;    // level > 0: rays per region of this level's queue
+    const float4 *q_o, *q_d;          // this level's rays
+    const float2 *hits;
+    unsigned int *occ;                // [chunk][slots_cap]
+    unsigned int slots_cap;
+    // k_shadow_gen
+    int chunk;
+    float4 *sq_o, *sq_d;              // [segment][slots_cap]
+    unsigned int *sq_counts;          // [segment][region]
+    // k_shade
+    float4 *records;
+    float *hit_t;
+    float4 *nq_o, *nq_d;
+    unsigned int *out_counts;         // next level's rays per region
+    FrameCounters *counters;
+};
+
+struct SlotRay { F3 o, d; int pixel; bool live; float t; int id; };
+
+template <bool PRIMARY>
+__device__ __forceinline__ unsigned int region_count(const ShadeArgs &A, int region)
+{
+    if (PRIMARY) {
+        const unsigned int r0 = (unsigned)region * REGION;
+        return A.n_slots > r0 ? min((unsigned)REGION, A.n_slots - r0) : 0u;
+    }
+    return A.in_counts[region];
+}
+
+template <bool PRIMARY>
+__device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int slot, bool in_range)
+{
+    SlotRay r;
+    r.live = in_range;
+    r.pixel = 0; r.t = FLT_MAX; r.id = -1;
+    r.o = mk(0.f, 0.f, 0.f); r.d = mk(0.f, 0.f, 1.f);
+    if (r.live) {
+        if (PRIMARY) {
+            const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, slot);
+            r.o = pr.o; r.d = pr.d; r.pixel = pr.pixel; r.live = pr.live;
+        } else {
+            const float4 qo = A.q_o[slot], qd = A.q_d[slot];
+            r.o = f3(qo); r.d = f3(qd); r.pixel = __float_as_int(qo.w);
+        }
+    }
+    if (r.live) {
+        const float2 h = A.hits[slot];
+        r.t = h.x; r.id = __float_as_int(h.y);
+        // never index scene arrays with an id outside the scene
+        if (r.id >= A.sc.n_analytic + A.sc.n_tris) r.id = -1;
+    }
+    return r;
+}
+
+// Rank of this thread among the block's threads with `flag` set, and the block total.
+// s_cnt: 4 LDS words.  Two barriers; every thread of the block must call it.
+__device__ __forceinline__ unsigned int block_rank(bool flag, unsigned int *s_cnt, unsigned int &total)
+{
+    const unsigned long long mask = __ballot(flag);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_cnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    unsigned int before = 0, all = 0;
+    for (int w = 0; w < BLOCK / 64; w++) {
+        const unsigned int c = s_cnt[w];
+        if (w < wave) before += c;
+        all += c;
+    }
+    __syncthreads();
+    total = all;
+    return before + (unsigned)__popcll(mask & lanemask_lt());
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
+{
+    __shared__ unsigned int s_cnt[BLOCK / 64];
+    const DevScene &sc = A.sc;
+    Tally tl = { 0u, 0u, 0u };
+    const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
+    for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
+        const unsigned int cnt = region_count<PRIMARY>(A, region);
+        const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
+        const SlotRay r = load_slot<PRIMARY>(A, slot, threadIdx.x < cnt);
+        bool lit = r.live && r.id >= 0;
+        if (lit && r.id < sc.n_analytic && sc.analytic[r.id].is_light) lit = false;       // main.cpp:166
+        const F3 pos = add(r.o, muls(r.d, r.t));                                          // main.cpp:163
+        unsigned int bits = 0;
+        for (int li = l0; li < l1; li++) {                                                // main.cpp:170-173
+            const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
+            bool want = false;
+            F3 L = mk(0.f, 0.f, 1.f), so = pos;
+            if (lit) {
+                L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));                       // main.cpp:178
+                so = add(pos, muls(L, 0.01f));                                            // main.cpp:179
+                if (analytic_occluded<false>(sc, so, L, tl)) bits |= 1u << (li - l0);
+                else want = true;
+            }
+            unsigned int total;
+            const unsigned int rank = block_rank(want, s_cnt, total);
+            if (want) {
+                const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)region * REGION + rank;
+                A.sq_o[q] = make_float4(so.x, so.y, so.z, __int_as_float((int)slot));
+                A.sq_d[q] = make_float4(L.x, L.y, L.z, __int_as_float(li - l0));
+            }
+            if (threadIdx.x == 0) A.sq_counts[(size_t)(li - l0) * A.n_regions + region] = total;
+        }
+        if (r.live) A.occ[(size_t)A.chunk * A.slots_cap + slot] = bits;
+    }
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(BLOCK) void k_shade(ShadeArgs A)
+{
+    __shared__ unsigned int s_cnt[BLOCK / 64];
+    __shared__ unsigned int s_stat[2];
+    const DevScene &sc = A.sc;
+    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+    unsigned int n_shadow = 0, n_reflect = 0;
+    for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
+        const unsigned int cnt = region_count<PRIMARY>(A, region);
+        const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
+        const SlotRay r = load_slot<PRIMARY>(A, slot, threadIdx.x < cnt);
+        const bool hit = r.live && r.id >= 0;
+        F3 col = mk(0.f, 0.f, 0.f), pos = mk(0.f, 0.f, 0.f);
+        Surface s;
+        s.N = mk(0.f, 0.f, 1.f); s.Mc = mk(0.f, 0.f, 0.f); s.kr = s.kd = s.ks = 0.f; s.emissive = false;
+        if (hit) {
+            pos = add(r.o, muls(r.d, r.t));                                               // main.cpp:163
+            s = surface_at(sc, r.id, pos);                                                // main.cpp:164
+        }
+        const bool lit = hit && !s.emissive;
+        if (hit && s.emissive) col = s.Mc;                                                // main.cpp:166-167
+        if (lit) {
+            n_shadow += (unsigned)sc.n_lights;
+            unsigned int bits = 0;
+            for (int li = 0; li < sc.n_lights; li++) {                                    // main.cpp:170-173
+                if ((li & 31) == 0) bits = A.occ[(size_t)(li >> 5) * A.slots_cap + slot];
+                const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
+                const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));             // main.cpp:178
+                const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;             // main.cpp:175, 185
+                const F3 Lc = mk(lt_.cr, lt_.cg, lt_.cb);
+                if (s.kd > 0.0f) {                                                        // main.cpp:191-195
+                    float diffuse = dot(s.N, L) * s.kd;
+                    col = add(col, muls(muls(mulv(Lc, s.Mc), diffuse), shade));
+                }
+                if (s.ks > 0.0f) {                                                        // main.cpp:198-204
+                    F3 R = sub(L, muls(muls(s.N, dot(L, s.N)), 2.0f));
+                    float dt = dot(r.d, R);
+                    if (dt > 0.0f)
+                        col = add(col, muls(muls(muls(mulv(Lc, s.Mc), pow20(dt)), s.ks), shade));
+                }
+            }
+        }
+        if (r.live) {
+            A.records[(size_t)A.level * (size_t)A.n_pixels + (size_t)r.pixel] =
+                make_float4(col.x, col.y, col.z, __int_as_float(r.id));
+            if (PRIMARY && A.hit_t) A.hit_t[r.pixel] = r.t;
+        }
+        const bool spawn = lit && s.kr > 0.0f && A.level < A.max_depth;                  // main.cpp:208
+        unsigned int total;
+        const unsigned int rank = block_rank(spawn, s_cnt, total);
+        if (spawn) {
+            const F3 R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));                  // main.cpp:210
+            const size_t dst = (size_t)region * REGION + rank;
+            A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));      // origin is pos itself (main.cpp:211)
+            A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
+            n_reflect++;
+        }
+        if (threadIdx.x == 0) A.out_counts[region] = total;
+    }
+    // ray counters: wave reduce -> LDS -> one atomic per block and counter
+    unsigned int vals[2] = { n_shadow, n_reflect };
+    for (int k = 0; k < 2; k++) {
+        unsigned int v = vals[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_stat[threadIdx.x])
+        atomicAdd(threadIdx.x == 0 ? &A.counters->rays_shadow : &A.counters->rays_reflect, (unsigned long long)s_stat[threadIdx.x]);
+}
+
+template <bool ANYHIT, bool PRIMARY>
+void launch_trace(const TraceArgs &a, bool count, int grid, hipStream_t stream)
+{
+    if (count) hipLaunchKernelGGL((k_trace<ANYHIT, PRIMARY, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_trace<ANYHIT, PRIMARY, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+}
+
+}  // namespace
+
+// Persistent traversal blocks per CU (8 = the LDS/VGPR residency limit).  RT_WF_BLOCKS_PER_CU
+// overrides it for occupancy experiments.
+int wavefront_trace_grid(int num_cus)
+{
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        const char *e = getenv("RT_WF_BLOCKS_PER_CU");
+        per_cu = e ? atoi(e) : 8;
+        if (per_cu < 1 || per_cu > 8) per_cu = 8;
+    }
+    return num_cus * per_cu;
+}
+size_t wavefront_overflow_ints(int num_cus) { return (size_t)WF_OVF * (size_t)wavefront_trace_grid(num_cus) * BLOCK; }
+size_t wavefront_regions(size_t slots) { return (slots + REGION - 1) / REGION; }
+// unsigned ints of per-frame claim cursors: one SHARDS-wide row per k_trace launch
+size_t wavefront_cursor_words(int levels, int n_chunks)
+{
+    return (size_t)SHARDS * CURSOR_STRIDE * (size_t)levels * (size_t)(1 + n_chunks);
+}
+
+int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_hit_t,
+                    hipStream_t stream, int num_cus, const std::function<int()> &stamp, int *n_launches, std::string *err)
+{
+    const int n_rows = fp.rows.n_rows;
+    const int n_pixels = fp.W * n_rows;
+    const int tiles = ((fp.W + 7) / 8) * ((n_rows + 7) / 8);
+    const unsigned int n_slots = (unsigned)tiles * 64u;
+    const int n_regions = (int)wavefront_regions(n_slots);
+    const int n_chunks = (scene.n_lights + 31) / 32;
+    const int trace_grid = wavefront_trace_grid(num_cus);
+    const bool count = fp.count_tests != 0;
+    if (fp.stack_depth + 1 > WF_LDS_STACK + WF_OVF) {
+        if (err) *err = "LBVH deeper than the traversal stack";
+        return RT_E_LIMIT;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(ws.trace_cursors, 0, sizeof(unsigned int) * wavefront_cursor_words(fp.max_depth + 1, n_chunks), stream),
+                 err);
+
+    TraceArgs t;
+    t.sc = scene; t.cam = cam; t.W = fp.W; t.n_rows = n_rows; t.rows = fp.rows;
+    t.hits = ws.hits;
+    t.n_slots = n_slots; t.n_regions = n_regions;
+    t.overflow = ws.overflow; t.total_lanes = (unsigned)trace_grid * BLOCK;
+    t.counters = ws.counters;
+
+    ShadeArgs s;
+    s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = n_rows; s.n_pixels = n_pixels; s.rows = fp.rows;
+    s.max_depth = fp.max_depth;
+    s.n_slots = n_slots; s.n_regions = n_regions;
+    s.hits = ws.hits;
+    s.occ = ws.occ; s.slots_cap = (unsigned)ws.slots_cap;
+    s.sq_o = ws.sq_o; s.sq_d = ws.sq_d; s.sq_counts = ws.sq_counts;
+    s.records = ws.records; s.hit_t = (float *)d_hit_t;
+    s.counters = ws.counters;
+
+    const int shade_grid = n_regions < num_cus * 8 ? n_regions : num_cus * 8;
+    unsigned int *cursor = ws.trace_cursors;
+    int launches = 0;
+    for (int level = 0; level <= fp.max_depth; level++) {
+        const bool primary = level == 0;
+        const float4 *qo = ws.queue_o[level & 1], *qd = ws.queue_d[level & 1];
+        const unsigned int *in_counts = ws.rq_counts[level & 1];
+        // ---- nearest hit
+        t.q_o = qo; t.q_d = qd;
+        t.occ = nullptr;
+        t.counts = in_counts;
+        t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
+        t.n_segments = 1; t.seg_stride = 0;
+        const int grid = (primary && n_regions * UPR < trace_grid * (BLOCK / 64)) ? (n_regions * UPR + 3) / 4 : trace_grid;
+        if (primary) launch_trace<false, true>(t, count, grid, stream);
+        else launch_trace<false, false>(t, count, grid, stream);
+        launches++;
+        // ---- shadows, 32 lights at a time
+        s.level = level;
+        s.q_o = qo; s.q_d = qd;
+        s.in_counts = in_counts;
+        s.nq_o = ws.queue_o[(level + 1) & 1]; s.nq_d = ws.queue_d[(level + 1) & 1];
+        s.out_counts = ws.rq_counts[(level + 1) & 1];
+        for (int chunk = 0; chunk < n_chunks; chunk++) {
+            s.chunk = chunk;
+            if (primary) hipLaunchKernelGGL(k_shadow_gen<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+            else hipLaunchKernelGGL(k_shadow_gen<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+            t.q_o = ws.sq_o; t.q_d = ws.sq_d;
+            t.occ = ws.occ + (size_t)chunk * ws.slots_cap;
+            t.counts = ws.sq_counts;
+            t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
+            t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;
+            t.seg_stride = (unsigned)ws.slots_cap;
+            launch_trace<true, false>(t, count, trace_grid, stream);
+            launches += 2;
+        }
+        // ---- local colour, record, reflection rays
+        if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        launches++;
+        if (int rc = stamp()) return rc;
+    }
+    RT_HIP_CHECK(hipGetLastError(), err);
+    *n_launches += launches;
+    return RT_OK;
+}
