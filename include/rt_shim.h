@@ -93,6 +93,7 @@ typedef struct {
     int32_t bvh_nodes, bvh_depth, bvh_leaf_max;
     int32_t accel;         /* 0 = linear scan over triangles, 1 = LBVH */
     float ms_build;        /* device time of the last LBVH build */
+    float ms_traverse;     /* LBVH scenes: sum of the traversal kernels alone (part of ms_trace) */
 } rt_stats;
 
 enum {

@@ -134,6 +134,8 @@ struct FrameWorkspace {
     uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr;
     size_t out_cap = 0;
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> trav_events;   // begin/end pairs around the traversal launches of the last frame
+    int trav_pairs = 0;
 };
 
 // trace.hip: enqueue one frame.  Outputs are device pointers (may be null).

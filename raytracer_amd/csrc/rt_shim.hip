@@ -38,6 +38,7 @@ struct rt_ctx {
     // last frame
     bool frame_valid = false;
     int last_levels = 0, last_launches = 0, last_accel = 0;
+    bool last_wavefront = false;
     uint64_t last_primary = 0;
 };
 
@@ -94,6 +95,7 @@ void free_workspace(FrameWorkspace &ws)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ws.trav_events) (void)hipEventDestroy(e);
     ws = FrameWorkspace();
 }
 
@@ -260,6 +262,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     c->last_levels = max_depth + 1;
     c->last_launches = launches;
     c->last_accel = accel;
+    c->last_wavefront = wavefront;
     c->last_primary = pixels;
     return RT_OK;
 }
@@ -580,6 +583,13 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
             out->ms_resolve = ms;
         if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)c->last_levels + 1]) == hipSuccess)
             out->ms_frame = ms;
+        out->ms_traverse = out->ms_trace;
+        if (c->last_wavefront && c->ws.trav_pairs > 0 && (int)c->ws.trav_events.size() >= 2 * c->ws.trav_pairs) {
+            float tv = 0.f;
+            for (int k = 0; k < c->ws.trav_pairs; k++)
+                if (hipEventElapsedTime(&ms, c->ws.trav_events[2 * (size_t)k], c->ws.trav_events[2 * (size_t)k + 1]) == hipSuccess) tv += ms;
+            out->ms_traverse = tv;
+        }
     }
     return RT_OK;
 }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
         const bool do_node = WF_VOTE ? (__popcll(m_node) >= __popcll(m_leaf)) : (m_node != 0ull);
         const bool do_leaf = WF_VOTE ? !do_node : (m_leaf != 0ull);
         if (do_node) {
-            // ---- inner-node step: both children's boxes from one 64-byte node
+            // ---- inner-node step: both children's lattice boxes from one 32-byte node
             if ((unsigned)node < SENT_U) {
                 const BvhNodeQ *np = sc.qnodes + node;
                 const uint4 qa = np->a, qb = np->b;
@@ -542,6 +542,19 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     const int shade_grid = n_regions < num_cus * 8 ? n_regions : num_cus * 8;
     unsigned int *cursor = ws.trace_cursors;
     int launches = 0;
+    // device events around every traversal launch (for rt_stats.ms_traverse)
+    size_t te = 0;
+    auto tstamp = [&]() -> int {
+        if (!fp.timing) return RT_OK;
+        if (te >= ws.trav_events.size()) {
+            hipEvent_t e;
+            RT_HIP_CHECK(hipEventCreate(&e), err);
+            ws.trav_events.push_back(e);
+        }
+        RT_HIP_CHECK(hipEventRecord(ws.trav_events[te++], stream), err);
+        return RT_OK;
+    };
+    ws.trav_pairs = 0;
     for (int level = 0; level <= fp.max_depth; level++) {
         const bool primary = level == 0;
         const float4 *qo = ws.queue_o[level & 1], *qd = ws.queue_d[level & 1];
@@ -553,8 +566,10 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
         t.n_segments = 1; t.seg_stride = 0;
         const int grid = (primary && n_regions * UPR < trace_grid * (BLOCK / 64)) ? (n_regions * UPR + 3) / 4 : trace_grid;
+        if (int rc = tstamp()) return rc;
         if (primary) launch_trace<false, true>(t, count, grid, stream);
         else launch_trace<false, false>(t, count, grid, stream);
+        if (int rc = tstamp()) return rc;
         launches++;
         // ---- shadows, 32 lights at a time
         s.level = level;
@@ -572,7 +587,9 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
             t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
             t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;
             t.seg_stride = (unsigned)ws.slots_cap;
+            if (int rc = tstamp()) return rc;
             launch_trace<true, false>(t, count, trace_grid, stream);
+            if (int rc = tstamp()) return rc;
             launches += 2;
         }
         // ---- local colour, record, reflection rays
@@ -582,6 +599,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         if (int rc = stamp()) return rc;
     }
     RT_HIP_CHECK(hipGetLastError(), err);
+    ws.trav_pairs = (int)(te / 2);
     *n_launches += launches;
     return RT_OK;
 }
