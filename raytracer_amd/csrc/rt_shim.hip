@@ -32,7 +32,7 @@ struct rt_ctx {
     int n_mats = 0;
     LbvhResult bvh;
     // options
-    int opt_accel = 0, opt_count = 0, opt_leaf_max = 4, opt_timing = 1, opt_pipeline = 0;
+    int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0;
     DevCamera cam;
     FrameWorkspace ws;
     // last frame

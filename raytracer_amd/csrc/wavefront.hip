@@ -43,12 +43,21 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 16
 #endif
+#ifndef WF_LEAF_LOOP
+#define WF_LEAF_LOOP 1
+#endif
+#ifndef WF_ANYHIT_NEAR
+#define WF_ANYHIT_NEAR 0
+#endif
+#ifndef WF_UNIT
+#define WF_UNIT 64
+#endif
 #ifndef WF_VOTE
 #define WF_VOTE 1
 #endif
 constexpr int REFILL_MIN = WF_REFILL_MIN; // refill once this many lanes of a wave are idle
 constexpr int REGION = BLOCK;             // slots per queue region = one producer block iteration
-constexpr int UNIT = 64;                  // rays per claimed work unit
+constexpr int UNIT = WF_UNIT;             // rays per claimed work unit
 constexpr int UPR = REGION / UNIT;        // units per region
 constexpr int SHARDS = 64;                // claim cursors per launch
 constexpr int CURSOR_STRIDE = 32;         // words between cursors: each on its own 128-byte line, because atomics
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
                 if (COUNT) tl.box += 2;
                 if (h0 && h1) {
-                    const bool swap = !ANYHIT && n1 < n0;
+                    const bool swap = (WF_ANYHIT_NEAR || !ANYHIT) && n1 < n0;
                     push(swap ? ch.x : ch.y);
                     node = swap ? ch.y : ch.x;
                 } else if (h0) {
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                     tri_i = leaf >> 3;
                     tri_left = (leaf & 7) + 1;
                 }
-#ifdef WF_LEAF_LOOP
+#if WF_LEAF_LOOP
                 for (;;) {
 #endif
                 const float4 v1 = sc.bvh_tri[3 * (size_t)tri_i];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                     const int id = sc.n_analytic + __float_as_int(v1.w);
                     if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
                 }
-#ifdef WF_LEAF_LOOP
+#if WF_LEAF_LOOP
                 if (node == NODE_SENTINEL || tri_left == 0) break;
                 }
 #endif
