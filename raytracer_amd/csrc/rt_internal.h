@@ -78,6 +78,8 @@ struct FrameCounters {
     unsigned int cursor[RT_MAX_DEPTH + 2];        // work-fetch cursor of each level
     unsigned long long rays_shadow, rays_reflect;
     unsigned long long box_tests, tri_tests, analytic_tests;
+    // RT_OPT_COUNT_TESTS only: wave iterations of each traversal step and the lanes that took part
+    unsigned long long node_iters, node_lanes, leaf_iters, leaf_lanes, refill_events, refill_lanes;
 };
 
 // ------------------------------------------------------------------ host-side state

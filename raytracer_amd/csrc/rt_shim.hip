@@ -3,6 +3,8 @@
 // here: every entry point either runs the HIP kernels or returns an error.
 #include "rt_internal.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -570,6 +572,11 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->box_tests = fc.box_tests;
     out->tri_tests = fc.tri_tests;
     out->analytic_tests = fc.analytic_tests;
+    if (c->opt_count && getenv("RT_WF_DEBUG") && fc.node_iters)
+        fprintf(stderr, "[rt] traversal: node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes), refills %llu (%.1f rays)\n",
+                fc.node_iters, (double)fc.node_lanes / (double)fc.node_iters, fc.leaf_iters,
+                fc.leaf_iters ? (double)fc.leaf_lanes / (double)fc.leaf_iters : 0.0, fc.refill_events,
+                fc.refill_events ? (double)fc.refill_lanes / (double)fc.refill_events : 0.0);
     out->n_launches = c->last_launches;
     out->accel = c->last_accel;
     if (c->opt_timing && (int)c->ws.events.size() >= c->last_levels + 2) {

@@ -52,6 +52,9 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_UNIT
 #define WF_UNIT 64
 #endif
+#ifndef WF_LEAF_MIN
+#define WF_LEAF_MIN 0
+#endif
 #ifndef WF_VOTE
 #define WF_VOTE 1
 #endif
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
     F3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f), oi = mk(0.f, 0.f, 0.f);
     float best_t = FLT_MAX;
     Tally tl = { 0u, 0u, 0u };
+    unsigned int dbg[6] = { 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes
 
     // ---- per-wave fetch state (uniform): local range [cur, end) of queue positions in segment `seg`
     unsigned int cur = 0, end = 0;
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                 if (cur >= end) continue;      // empty unit
             }
             const unsigned int my = cur + (unsigned)__popcll(idle & lt);
+            if (COUNT) { dbg[4]++; dbg[5] += min((unsigned)__popcll(idle), end - cur); }
             if (node == NODE_SENTINEL && my < end) {
                 bool live = true;
                 if (ANYHIT) {
@@ -206,8 +211,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
             continue;
         }
 
-        const bool do_node = WF_VOTE ? (__popcll(m_node) >= __popcll(m_leaf)) : (m_node != 0ull);
+        const bool do_node = WF_VOTE ? (WF_LEAF_MIN ? (__popcll(m_leaf) < WF_LEAF_MIN && m_node != 0ull) : (__popcll(m_node) >= __popcll(m_leaf)))
+                                     : (m_node != 0ull);
         const bool do_leaf = WF_VOTE ? !do_node : (m_leaf != 0ull);
+        if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); }
+        if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
         if (do_node) {
             // ---- inner-node step: both children's lattice boxes from one 32-byte node
             if ((unsigned)node < SENT_U) {
@@ -288,6 +296,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0 && v)
                 atomicAdd(k == 0 ? &A.counters->box_tests : k == 1 ? &A.counters->tri_tests : &A.counters->analytic_tests, v);
+        }
+        if (lane == 0) {
+            unsigned long long *dst = &A.counters->node_iters;
+            for (int k = 0; k < 6; k++)
+                if (dbg[k]) atomicAdd(dst + k, (unsigned long long)dbg[k]);
         }
     }
 }

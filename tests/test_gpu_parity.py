@@ -306,3 +306,46 @@ def test_host_application_loads_an_obj_and_writes_float_and_id_planes():
     cam = rt.camera_for_width(400)
     r = to_oracle(spec).render(400, 300, max_depth=4, cam=ocam(cam), threads=8)
     assert_parity(compare(dict(rgb8=img, hit_id=hid, rgb32=f32), r))
+
+
+# ------------------------------------------------------------------ many lights / no lights through the LBVH stages
+def _ring_of_lights(n):
+    from common import sphere
+    out = []
+    for k in range(n):
+        a = 2.0 * np.pi * k / n
+        c = (0.5 + 0.5 * np.cos(3 * a), 0.5 + 0.5 * np.sin(5 * a), 0.6)
+        out.append(sphere((4.0 * np.cos(a), 3.0 + 0.5 * np.sin(2 * a), 1.0 + 4.0 * np.sin(a)), 0.05,
+                          (0.0, 1.0, 1.0, tuple(0.05 * x for x in c)), True))
+    return out
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 31, 32, 33, 70])
+def test_light_counts_across_the_32_light_chunks(n_lights):
+    """Shadow rays are traced 32 lights at a time; counts on and around the chunk edges."""
+    from common import SceneSpec, plane
+    v, i, m = scenes.atrium_mesh(detail=0.004)
+    spec = SceneSpec(_ring_of_lights(n_lights) + [plane((0.0, 1.0, 0.0), -4.5, (0.3, 1.0, 1.0, (1.0, 1.0, 1.0)))], v, i,
+                     (0.5, 1.0, 1.0, (1.0, 1.0, 1.0)))
+    cam = rt.camera_for_width(96)
+    r = to_oracle(spec).render(96, 54, max_depth=2, cam=ocam(cam), threads=16)
+    g = render(spec, 96, 54, 2, cam, rt.ACCEL_LBVH)
+    assert g["stats"]["accel"] == 1
+    c = compare(g, r)
+    assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0, c
+    assert c["rgb32_max_abs"] <= RGB32_TOL * max(1, n_lights), c
+    assert rays(g["stats"]) == orays(r)
+
+
+def test_fused_and_staged_pipelines_agree_bit_for_bit():
+    spec = atrium_spec(detail=0.02)
+    cam = rt.camera_for_width(320)
+    outs = []
+    for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_PIPELINE, pipeline)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            outs.append(ctx.render_frame(320, 180, max_depth=4))
+    for k in ("rgb8", "hit_id", "rgb32"):
+        assert np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8)), k
