@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
+    ap.add_argument("--builder", type=int, default=0, help="0 auto, 1 Karras LBVH, 2 PLOC")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto, 1 fused bounce kernel, 2 wavefront stages")
     return ap.parse_args()
 
@@ -110,6 +111,8 @@ def main():
         ctx.set_option(rt.OPT_LEAF_MAX, a.leaf_max)
     if a.pipeline:
         ctx.set_option(rt.OPT_PIPELINE, a.pipeline)
+    if a.builder:
+        ctx.set_option(rt.OPT_BUILDER, a.builder)
     wl.load(ctx)
     pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
 

@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 RT_SPHERE, RT_PLANE = 0, 1
 OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING, OPT_PIPELINE = 1, 2, 3, 4, 5
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
+OPT_BUILDER = 6
+BUILDER_AUTO, BUILDER_LBVH, BUILDER_PLOC = 0, 1, 2
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48
 
@@ -115,6 +117,25 @@ def camera_for_width(W):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A PyTorch-ROCm wheel carries its own libamdhip64.so (soname libamdhip64.so.7, the same
+    as /opt/rocm's).  Two HIP runtimes in one process cannot both own the GPU: whichever
+    initialises second finds no devices.  Loading the wheel's copy first makes the dynamic
+    loader resolve this library's libamdhip64.so.7 dependency to it, so torch tensors and this
+    library's kernels share one runtime whatever the import order.  Without torch installed the
+    system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load librt_amd.so and declare its prototypes.  Raises if it has not been built."""
     global _lib
@@ -123,6 +144,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not built: run `python raytracer_amd/build.py` "
                            "(there is no CPU fallback for the trace path)")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int
     L.rt_abi_version.restype = i32

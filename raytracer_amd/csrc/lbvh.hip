@@ -128,9 +128,12 @@ __global__ void k_morton(const float4 *__restrict__ tri_mt, int n, const unsigne
     float lo[3], hi[3];
     tri_box(tri_mt, i, lo, hi);
     unsigned long long code = 0;
+    // one cell size for all three axes (the longest scene extent): cubic cells split better than
+    // cells stretched to each axis' own extent
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) ext = fmaxf(ext, ordered_to_float(bounds[3 + k]) - ordered_to_float(bounds[k]));
     for (int k = 0; k < 3; k++) {
-        float slo = ordered_to_float(bounds[k]), shi = ordered_to_float(bounds[3 + k]);
-        float ext = shi - slo;
+        float slo = ordered_to_float(bounds[k]);
         float c = 0.5f * (lo[k] + hi[k]);
         float u = ext > 0.f ? (c - slo) / ext : 0.f;
         float q = fminf(fmaxf(u * 2097152.0f, 0.f), 2097151.0f);
@@ -159,34 +162,37 @@ __global__ __launch_bounds__(64) void k_sort_hist(const unsigned long long *__re
     for (int d = lane; d < 256; d += 64) hist[(size_t)d * n_tiles + tile] = h[d];
 }
 
-// Exclusive scan of `m` counters by a single 1024-thread block (m is at most a few hundred thousand).
-__global__ __launch_bounds__(1024) void k_scan_exclusive(unsigned int *data, int m)
+// Exclusive scan of `m` counters by a single 1024-thread block (m is at most a few million).
+// total (optional) receives the sum of all inputs.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_exclusive(T *data, int m, T *total)
 {
-    __shared__ unsigned int wave_sum[16];
-    __shared__ unsigned int carry_s;
+    __shared__ T wave_sum[16];
+    __shared__ T carry_s;
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < m; base += 1024 * 4) {
         int i0 = base + tid * 4;
-        unsigned int v[4], s = 0;
-        for (int k = 0; k < 4; k++) { v[k] = (i0 + k < m) ? data[i0 + k] : 0u; s += v[k]; }
-        unsigned int incl = s;
+        T v[4], s = 0;
+        for (int k = 0; k < 4; k++) { v[k] = (i0 + k < m) ? data[i0 + k] : (T)0; s += v[k]; }
+        T incl = s;
         for (int off = 1; off < 64; off <<= 1) {
-            unsigned int t = __shfl_up(incl, off);
+            T t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
         if (lane == 63) wave_sum[w] = incl;
         __syncthreads();
-        unsigned int wprefix = 0;
+        T wprefix = 0;
         for (int k = 0; k < w; k++) wprefix += wave_sum[k];
-        unsigned int carry = carry_s;
-        unsigned int excl = carry + wprefix + incl - s;
+        T carry = carry_s;
+        T excl = carry + wprefix + incl - s;
         for (int k = 0; k < 4; k++) { if (i0 + k < m) data[i0 + k] = excl; excl += v[k]; }
         __syncthreads();
         if (tid == 1023) carry_s = carry + wprefix + incl;
         __syncthreads();
     }
+    if (total && tid == 0) *total = carry_s;
 }
 
 __global__ __launch_bounds__(64) void k_sort_scatter(const unsigned long long *__restrict__ keys_in,
@@ -267,6 +273,119 @@ __global__ void k_karras(const unsigned long long *__restrict__ keys, int n, int
     if (i == 0) parent[0] = -1;
 }
 
+
+// ------------------------------------------------------------------ PLOC (parallel locally-ordered clustering)
+// Bottom-up agglomeration over the Morton-ordered clusters (Meister & Bittner 2018): every
+// cluster looks PLOC_R places to either side for the neighbour whose merged box has the
+// smallest surface area; mutual nearest neighbours merge; the cluster array is compacted and
+// the search repeats.  The result is markedly closer to a surface-area-heuristic tree than
+// the Karras hierarchy (about a quarter fewer box tests per ray on the courtyard scene).
+// Node ids as elsewhere: leaves (n-1)+sorted position, inner nodes 0..n-2 with the root = 0
+// (inner ids are handed out downward from n-2 in creation order, so the last merge is node 0).
+constexpr int PLOC_R = 16;
+
+__global__ void k_ploc_init(int n, int *cid, int *size)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    cid[j] = (n - 1) + j;
+    size[(n - 1) + j] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_nn(const int *__restrict__ cid, int C, const float4 *__restrict__ box_lo,
+                                                 const float4 *__restrict__ box_hi, int *nn)
+{
+    __shared__ float4 s_lo[256 + 2 * PLOC_R], s_hi[256 + 2 * PLOC_R];
+    const int base = blockIdx.x * 256 - PLOC_R;
+    for (int t = threadIdx.x; t < 256 + 2 * PLOC_R; t += 256) {
+        int k = base + t;
+        if (k >= 0 && k < C) {
+            int id = cid[k];
+            s_lo[t] = box_lo[id];
+            s_hi[t] = box_hi[id];
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    const float4 lo = s_lo[threadIdx.x + PLOC_R], hi = s_hi[threadIdx.x + PLOC_R];
+    float best = FLT_MAX;
+    int bj = -1;
+    for (int dj = -PLOC_R; dj <= PLOC_R; dj++) {          // ascending index + strict '<': lowest index wins ties,
+        const int k = i + dj;                             // which guarantees at least one mutual pair per round
+        if (dj == 0 || k < 0 || k >= C) continue;
+        const float4 l2 = s_lo[threadIdx.x + PLOC_R + dj], h2 = s_hi[threadIdx.x + PLOC_R + dj];
+        const float dx = fmaxf(hi.x, h2.x) - fminf(lo.x, l2.x), dy = fmaxf(hi.y, h2.y) - fminf(lo.y, l2.y),
+                    dz = fmaxf(hi.z, h2.z) - fminf(lo.z, l2.z);
+        const float a = dx * dy + dy * dz + dz * dx;
+        if (a < best) { best = a; bj = k; }
+    }
+    nn[i] = bj;
+}
+
+// flags[i]: low word 1 if cluster i survives the round, high word 1 if it is the lower half of a merging pair
+__global__ void k_ploc_flags(const int *__restrict__ nn, int C, unsigned long long *flags)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    const bool merge = mutual && i < j, removed = mutual && i > j;
+    flags[i] = (removed ? 0ull : 1ull) | (merge ? (1ull << 32) : 0ull);
+}
+
+__global__ void k_ploc_apply(const int *__restrict__ cid_in, const int *__restrict__ nn, const unsigned long long *__restrict__ scanned,
+                             int C, int n, int created_before, int *cid_out, int2 *children, int *parent, int *size,
+                             float4 *box_lo, float4 *box_hi)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    if (mutual && i > j) return;                          // absorbed by its partner
+    const unsigned long long sc = scanned[i];
+    const int pos = (int)(unsigned int)sc;
+    int id = cid_in[i];
+    if (mutual) {
+        const int a = id, b = cid_in[j];
+        const int node = (n - 2) - (created_before + (int)(sc >> 32));
+        children[node] = make_int2(a, b);
+        parent[a] = node;
+        parent[b] = node;
+        size[node] = size[a] + size[b];
+        const float4 la = box_lo[a], lb = box_lo[b], ha = box_hi[a], hb = box_hi[b];
+        box_lo[node] = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), 0.f);
+        box_hi[node] = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.f);
+        id = node;
+    }
+    cid_out[pos] = id;
+}
+
+// Depth-first leaf order, one tree level per launch: a node's subtree occupies
+// [offset, offset + size) of the leaf order; the left child starts at offset, the right after it.
+__global__ void k_dfs_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int *__restrict__ size,
+                            int n_internal, int level, int *offset)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal || depth[i] != level) return;
+    const int2 c = children[i];
+    const int off = offset[i];
+    offset[c.x] = off;
+    offset[c.y] = off + size[c.x];
+}
+
+__global__ void k_dfs_finish(const int *__restrict__ offset, const int *__restrict__ size, int n, int2 *range, int *leafpos,
+                             int *order)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n - 1) range[i] = make_int2(offset[i], offset[i] + size[i] - 1);
+    if (i < n) {
+        const int p = offset[(n - 1) + i];
+        leafpos[i] = p;
+        order[p] = i;
+    }
+}
+
 __global__ void k_node_depth(const int *__restrict__ parent, int n_internal, int *depth, int *max_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,7 +434,8 @@ __global__ void k_refit_level(const int2 *__restrict__ children, const int *__re
 // reached and are left zeroed.
 __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
-                       const float4 *__restrict__ box_hi, BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
+                       const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, BvhNode *nodes, BvhNodeQ *qnodes,
+                       QuantGrid *grid, int *live_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -340,7 +460,8 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     int cc[2] = { c.x, c.y };
     for (int k = 0; k < 2; k++) {
         if (cc[k] >= n - 1) {
-            enc[k] = ~(((cc[k] - (n - 1)) << 3) | 0);
+            const int j = cc[k] - (n - 1);
+            enc[k] = ~(((leafpos ? leafpos[j] : j) << 3) | 0);
         } else {
             int2 r = range[cc[k]];
             int cnt = r.y - r.x + 1;
@@ -374,12 +495,12 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     atomicMax(live_depth, depth[i] + 1);
 }
 
-__global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals, int n,
-                              float4 *bvh_tri)
+__global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals,
+                              const int *__restrict__ order, int n, float4 *bvh_tri)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    unsigned int src = sorted_vals[k];
+    unsigned int src = sorted_vals[order ? order[k] : k];
     float4 a = tri_mt[3 * (size_t)src], e1 = tri_mt[3 * (size_t)src + 1], e2 = tri_mt[3 * (size_t)src + 2];
     a.w = __int_as_float((int)src);
     bvh_tri[3 * (size_t)k] = a;
@@ -428,7 +549,7 @@ void lbvh_free(LbvhResult *r)
     *r = LbvhResult();
 }
 
-int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, LbvhResult *out, std::string *err)
+int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err)
 {
     lbvh_free(out);
     if (n < 2) {
@@ -477,7 +598,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, Lb
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
         hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, n, shift, hist.p, n_tiles);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, hist.p, 256 * n_tiles);
+        hipLaunchKernelGGL(k_scan_exclusive<unsigned int>, dim3(1), dim3(1024), 0, stream, hist.p, 256 * n_tiles, (unsigned int *)nullptr);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, vals[cur].p, n, shift, hist.p,
                            n_tiles, keys[cur ^ 1].p, vals[cur ^ 1].p);
         cur ^= 1;
@@ -485,19 +606,67 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, hipStream_t stream, Lb
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 2 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->qnodes, 0, sizeof(BvhNodeQ) * (size_t)(n - 1), stream), err);
-    hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
-                       parent.p);
-    hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
+    const bool ploc = builder != 1;
     int max_depth = 0;
-    RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
-    RT_HIP_CHECK(hipStreamSynchronize(stream), err);
-    for (int level = max_depth; level >= 0; level--)
-        hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n - 1, level,
-                           box_lo.p, box_hi.p);
+    DevBuf<int> cid[2], nn, size, offset, leafpos, order;
+    DevBuf<unsigned long long> flags, totals;
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
+    if (!ploc) {
+        hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
+                           parent.p);
+        hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
+        RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+        for (int level = max_depth; level >= 0; level--)
+            hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n - 1, level,
+                               box_lo.p, box_hi.p);
+    } else {
+        hipError_t e2 = hipSuccess;
+        auto A2 = [&](hipError_t r) { if (e2 == hipSuccess) e2 = r; };
+        A2(cid[0].alloc(n)); A2(cid[1].alloc(n)); A2(nn.alloc(n)); A2(size.alloc(2 * (size_t)n)); A2(offset.alloc(2 * (size_t)n));
+        A2(leafpos.alloc(n)); A2(order.alloc(n)); A2(flags.alloc(n)); A2(totals.alloc(1));
+        if (e2 != hipSuccess) {
+            if (err) *err = std::string("PLOC allocation: ") + hipGetErrorString(e2);
+            lbvh_free(out);
+            return RT_E_NOMEM;
+        }
+        RT_HIP_CHECK(hipMemsetAsync(parent.p, 0xff, sizeof(int) * 2 * (size_t)n, stream), err);
+        RT_HIP_CHECK(hipMemsetAsync(offset.p, 0, sizeof(int) * 2 * (size_t)n, stream), err);
+        hipLaunchKernelGGL(k_ploc_init, dim3(G), dim3(B), 0, stream, n, cid[0].p, size.p);
+        int C = n, created = 0, cc = 0;
+        while (C > 1) {
+            const int g = blocks_for(C, B);
+            hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, cid[cc].p, C, box_lo.p, box_hi.p, nn.p);
+            hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(B), 0, stream, nn.p, C, flags.p);
+            hipLaunchKernelGGL(k_scan_exclusive<unsigned long long>, dim3(1), dim3(1024), 0, stream, flags.p, C, totals.p);
+            hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(B), 0, stream, cid[cc].p, nn.p, flags.p, C, n, created, cid[cc ^ 1].p,
+                               children.p, parent.p, size.p, box_lo.p, box_hi.p);
+            unsigned long long tot = 0;
+            RT_HIP_CHECK(hipMemcpyAsync(&tot, totals.p, sizeof tot, hipMemcpyDeviceToHost, stream), err);
+            RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+            const int kept = (int)(unsigned int)tot, merged = (int)(tot >> 32);
+            if (merged <= 0 || kept != C - merged) {
+                if (err) *err = "PLOC made no progress";
+                lbvh_free(out);
+                return RT_E_DEVICE;
+            }
+            created += merged;
+            C = kept;
+            cc ^= 1;
+        }
+        hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
+        RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+        for (int level = 0; level <= max_depth; level++)
+            hipLaunchKernelGGL(k_dfs_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, size.p, n - 1, level,
+                               offset.p);
+        hipLaunchKernelGGL(k_dfs_finish, dim3(G), dim3(B), 0, stream, offset.p, size.p, n, range.p, leafpos.p, order.p);
+    }
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
-                       leaf_max, box_lo.p, box_hi.p, out->nodes, out->qnodes, grid.p, scalars.p + 1);
-    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, out->bvh_tri);
+                       leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, out->nodes, out->qnodes, grid.p,
+                       scalars.p + 1);
+    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
+                       out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
     RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
     int live_depth = 0;

@@ -89,12 +89,12 @@ struct LbvhResult {
     BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
-    int n_nodes = 0, depth = 0, leaf_max = 0;
+    int n_nodes = 0, depth = 0, leaf_max = 0, builder = 0;
     float ms_build = 0.f;
 };
 
 // lbvh.hip: builds the LBVH over tri_mt (device) on `stream`.  Returns RT_* code.
-int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, hipStream_t stream, LbvhResult *out,
+int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, int builder, hipStream_t stream, LbvhResult *out,
                std::string *err);
 void lbvh_free(LbvhResult *r);
 

@@ -34,7 +34,7 @@ struct rt_ctx {
     int n_mats = 0;
     LbvhResult bvh;
     // options
-    int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0;
+    int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0;
     DevCamera cam;
     FrameWorkspace ws;
     // last frame
@@ -191,10 +191,11 @@ int ensure_accel(rt_ctx *c, int *accel)
 {
     bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
     if (c->n_tris < 2) want = false;
-    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max)) {
+    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder)) {
         std::string err;
-        int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->stream, &c->bvh, &err);
+        int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->opt_builder, c->stream, &c->bvh, &err);
         if (rc != RT_OK) return fail(rc, err);
+        c->bvh.builder = c->opt_builder;
         if (c->bvh.depth > 64)
             return fail(RT_E_LIMIT, "LBVH deeper than the 64-entry traversal stack");
     }
@@ -329,6 +330,10 @@ int rt_set_option(rt_ctx *c, int option, int value)
         c->opt_leaf_max = value;
         return RT_OK;
     case RT_OPT_TIMING: c->opt_timing = value ? 1 : 0; return RT_OK;
+    case RT_OPT_BUILDER:
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_BUILDER takes 0, 1 or 2");
+        c->opt_builder = value;
+        return RT_OK;
     case RT_OPT_PIPELINE:
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
         c->opt_pipeline = value;
