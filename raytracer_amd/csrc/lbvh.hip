@@ -439,10 +439,10 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
-    // 16-bit lattice over the root box (the union of all padded leaf boxes)
+    // 15-bit lattice over the root box (the union of all padded leaf boxes)
     const float4 rlo = box_lo[0], rhi = box_hi[0];
     const float gb[3] = { rlo.x, rlo.y, rlo.z };
-    float gs[3] = { (rhi.x - rlo.x) * (1.0f / 65535.0f), (rhi.y - rlo.y) * (1.0f / 65535.0f), (rhi.z - rlo.z) * (1.0f / 65535.0f) };
+    float gs[3] = { (rhi.x - rlo.x) * (1.0f / 32767.0f), (rhi.y - rlo.y) * (1.0f / 32767.0f), (rhi.z - rlo.z) * (1.0f / 32767.0f) };
     for (int k = 0; k < 3; k++)
         if (!(gs[k] > 0.0f)) gs[k] = 1e-30f;
     if (i == 0) {
@@ -483,9 +483,11 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
         for (int k = 0; k < 3; k++) {
             double ql = floor(((double)lo[c2][k] - (double)gb[k]) / (double)gs[k]);
             double qh = ceil(((double)hi[c2][k] - (double)gb[k]) / (double)gs[k]);
-            ql = fmin(fmax(ql, 0.0), 65535.0);
-            qh = fmin(fmax(qh, 0.0), 65535.0);
-            w[c2 * 3 + k] = (unsigned int)ql | ((unsigned int)qh << 16);
+            ql = fmin(fmax(ql, 0.0), 32767.0);
+            qh = fmin(fmax(qh, 0.0), 32767.0);
+            // bit 15 of each half is always set: placed in bytes 1-2 under an exponent byte 0x3f the half
+            // reads as the float 1 + q/32768, so the traversal needs no integer-to-float conversion
+            w[c2 * 3 + k] = (0x8000u | (unsigned int)ql) | ((0x8000u | (unsigned int)qh) << 16);
         }
     }
     BvhNodeQ qn;

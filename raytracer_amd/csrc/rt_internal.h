@@ -42,8 +42,8 @@ struct BvhNode {
     int4 ch;      // child0, child1, unused, unused
 };
 
-// The same node with its boxes rounded outward onto a 16-bit lattice over the root box, 32 B:
-// world = base + q * step per axis (QuantGrid).  Half the bytes per traversal step.
+// The same node with its boxes rounded outward onto a 15-bit lattice over the root box, 32 B
+// (each 16-bit half is 0x8000 | q): world = base + q * step per axis (QuantGrid).  Half the bytes per traversal step.
 struct BvhNodeQ {
     uint4 a;      // child0 x (lo | hi << 16), child0 y, child0 z, child1 x
     uint4 b;      // child1 y, child1 z, child0 ref, child1 ref

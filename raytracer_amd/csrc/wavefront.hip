@@ -55,6 +55,14 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_LEAF_MIN
 #define WF_LEAF_MIN 0
 #endif
+#ifndef WF_WAVES_EU
+#define WF_WAVES_EU 8      // > 0: register budget for this many k_trace waves per SIMD (8 = the persistent grid's residency)
+#endif
+#if WF_WAVES_EU
+#define WF_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(WF_WAVES_EU, WF_WAVES_EU)))
+#else
+#define WF_TRACE_ATTR
+#endif
 #ifndef WF_VOTE
 #define WF_VOTE 1
 #endif
@@ -66,6 +74,10 @@ constexpr int SHARDS = 64;                // claim cursors per launch
 constexpr int CURSOR_STRIDE = 32;         // words between cursors: each on its own 128-byte line, because atomics
                                           // to one line serialise (~90 per microsecond) wherever in the line they land
 constexpr int MAX_PROBES = 8;             // shards a wave tries (its own first) before it stops claiming
+// v_perm_b32 selectors that lift one 16-bit half of a packed plane pair into float bits
+// 0x3f000000 | half << 8 (bit 15 of every stored half is set, so this is 1 + q/32768): byte 3 from the
+// constant operand, bytes 2-1 from the half, byte 0 zero.
+constexpr unsigned int SEL_LO = 0x0401000cu, SEL_HI = 0x0403020cu, PERM_EXP = 0x3f3f3f3fu;
 constexpr float INV_MAX = 1e30f;          // stands in for 1/0 so that lo*inv - o*inv stays finite
 
 struct TraceArgs {
@@ -86,8 +98,21 @@ struct TraceArgs {
     FrameCounters *counters;
 };
 
+typedef float V2 __attribute__((ext_vector_type(2)));
+
+// Entry (x) and exit (y) parameter of the ray against one axis' plane pair, packed lo | hi << 16 on
+// the lattice: sel_n / sel_f pick the half the ray meets first / last, and t = f*s + b with
+// f = 1 + q/32768 read straight from the permuted bits.
+__device__ __forceinline__ V2 plane_pair(unsigned int w, unsigned int sel_n, unsigned int sel_f, float s, float b)
+{
+    const V2 f = { __uint_as_float(__builtin_amdgcn_perm(PERM_EXP, w, sel_n)),
+                   __uint_as_float(__builtin_amdgcn_perm(PERM_EXP, w, sel_f)) };
+    const V2 sv = { s, s }, bv = { b, b };
+    return __builtin_elementwise_fma(f, sv, bv);
+}
+
 template <bool ANYHIT, bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
+__global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
 {
     __shared__ int s_stack[WF_LDS_STACK * BLOCK];
     const int lane = threadIdx.x & 63;
@@ -100,6 +125,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
     int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = 0;
     unsigned int slot = 0;
     F3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f), oi = mk(0.f, 0.f, 0.f);
+    uint3 sel_n = make_uint3(SEL_LO, SEL_LO, SEL_LO), sel_f = make_uint3(SEL_HI, SEL_HI, SEL_HI);
     float best_t = FLT_MAX;
     Tally tl = { 0u, 0u, 0u };
     unsigned int dbg[6] = { 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes
@@ -192,9 +218,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                     // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf
                     inv = mk(fminf(fmaxf(1.0f / d.x, -INV_MAX), INV_MAX), fminf(fmaxf(1.0f / d.y, -INV_MAX), INV_MAX),
                              fminf(fmaxf(1.0f / d.z, -INV_MAX), INV_MAX));
-                    // lattice plane q maps to t = q*(step*inv) + (base - o)*inv
+                    sel_n = make_uint3(inv.x < 0.0f ? SEL_HI : SEL_LO, inv.y < 0.0f ? SEL_HI : SEL_LO, inv.z < 0.0f ? SEL_HI : SEL_LO);
+                    sel_f = make_uint3(inv.x < 0.0f ? SEL_LO : SEL_HI, inv.y < 0.0f ? SEL_LO : SEL_HI, inv.z < 0.0f ? SEL_LO : SEL_HI);
+                    // lattice plane q (read as f = 1 + q/32768) maps to t = f*(32768*step*inv) + ((base - o)*inv - 32768*step*inv)
                     oi = mk((sc.grid.base[0] - o.x) * inv.x, (sc.grid.base[1] - o.y) * inv.y, (sc.grid.base[2] - o.z) * inv.z);
-                    inv = mk(sc.grid.step[0] * inv.x, sc.grid.step[1] * inv.y, sc.grid.step[2] * inv.z);
+                    inv = mk(sc.grid.step[0] * 32768.0f * inv.x, sc.grid.step[1] * 32768.0f * inv.y, sc.grid.step[2] * 32768.0f * inv.z);
+                    oi = mk(oi.x - inv.x, oi.y - inv.y, oi.z - inv.z);
                     stack[0] = NODE_SENTINEL;
                     sp = 1;
                     tri_left = 0;
@@ -223,20 +252,17 @@ __global__ __launch_bounds__(BLOCK) void k_trace(TraceArgs A)
                 const uint4 qa = np->a, qb = np->b;
                 const int2 ch = make_int2((int)qb.z, (int)qb.w);
                 const float tmax = ANYHIT ? FLT_MAX : best_t;
-                // one fma per box plane; the lattice boxes contain the padded float boxes
-                float a, b;
-                a = fmaf((float)(qa.x & 0xffffu), inv.x, oi.x); b = fmaf((float)(qa.x >> 16), inv.x, oi.x);
-                float n0 = fminf(a, b), f0 = fmaxf(a, b);
-                a = fmaf((float)(qa.y & 0xffffu), inv.y, oi.y); b = fmaf((float)(qa.y >> 16), inv.y, oi.y);
-                n0 = fmaxf(n0, fminf(a, b)); f0 = fminf(f0, fmaxf(a, b));
-                a = fmaf((float)(qa.z & 0xffffu), inv.z, oi.z); b = fmaf((float)(qa.z >> 16), inv.z, oi.z);
-                n0 = fmaxf(fmaxf(n0, fminf(a, b)), 0.0f); f0 = fminf(fminf(f0, fmaxf(a, b)), tmax);
-                a = fmaf((float)(qa.w & 0xffffu), inv.x, oi.x); b = fmaf((float)(qa.w >> 16), inv.x, oi.x);
-                float n1 = fminf(a, b), f1 = fmaxf(a, b);
-                a = fmaf((float)(qb.x & 0xffffu), inv.y, oi.y); b = fmaf((float)(qb.x >> 16), inv.y, oi.y);
-                n1 = fmaxf(n1, fminf(a, b)); f1 = fminf(f1, fmaxf(a, b));
-                a = fmaf((float)(qb.y & 0xffffu), inv.z, oi.z); b = fmaf((float)(qb.y >> 16), inv.z, oi.z);
-                n1 = fmaxf(fmaxf(n1, fminf(a, b)), 0.0f); f1 = fminf(fminf(f1, fmaxf(a, b)), tmax);
+                // one fma per box plane; the lattice boxes contain the padded float boxes.  The ray's
+                // direction signs decide which plane of each pair is entered first, so no min/max per axis;
+                // one v_perm_b32 per plane builds its float, and the two planes of a pair share a packed fma.
+                const V2 x0 = plane_pair(qa.x, sel_n.x, sel_f.x, inv.x, oi.x), y0 = plane_pair(qa.y, sel_n.y, sel_f.y, inv.y, oi.y),
+                         z0 = plane_pair(qa.z, sel_n.z, sel_f.z, inv.z, oi.z);
+                const V2 x1 = plane_pair(qa.w, sel_n.x, sel_f.x, inv.x, oi.x), y1 = plane_pair(qb.x, sel_n.y, sel_f.y, inv.y, oi.y),
+                         z1 = plane_pair(qb.y, sel_n.z, sel_f.z, inv.z, oi.z);
+                const float n0 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x0.x, y0.x), z0.x), 0.0f);
+                const float f0 = fminf(__builtin_fminf(__builtin_fminf(x0.y, y0.y), z0.y), tmax);
+                const float n1 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x1.x, y1.x), z1.x), 0.0f);
+                const float f1 = fminf(__builtin_fminf(__builtin_fminf(x1.y, y1.y), z1.y), tmax);
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
                 if (COUNT) tl.box += 2;
                 if (h0 && h1) {
