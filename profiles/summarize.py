@@ -34,7 +34,7 @@ def main(d):
                 calls[k].add(r["Dispatch_Id"])
         print("== counters per launch:", os.path.basename(p))
         for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
-            if not any(t in k for t in ("k_bounce", "k_resolve", "k_trace", "k_shade", "k_shadow_gen")):
+            if not any(t in k for t in ("k_bounce", "k_resolve", "k_trace", "k_shade", "k_shadow_gen", "k_stream")):
                 continue
             n = max(len(calls[k]), 1)
             print("  %-46s launches %3d  " % (k, n) + "  ".join("%s=%.4g" % (c, v / n) for c, v in sorted(acc[k].items())))

@@ -1,0 +1,22 @@
+"""Print the kernel timeline of the last frame from a rocprofv3 --kernel-trace csv directory:
+start offset, duration and gap to the previous kernel's end (all in microseconds)."""
+import csv, glob, os, sys
+
+def main(d):
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    # last frame = from the last level-0 primary k_trace to the end
+    names = [r["Kernel_Name"] for r in rows]
+    starts = [i for i, n in enumerate(names) if "k_trace<false, true" in n]
+    i0 = starts[-2] if len(starts) > 1 else starts[-1]
+    i1 = starts[-1] if len(starts) > 1 else len(rows)
+    t0 = int(rows[i0]["Start_Timestamp"]); prev_end = t0
+    for r in rows[i0:i1]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        print("%9.1f  dur %8.1f  gap %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, n[:50]))
+        prev_end = max(prev_end, e)
+    print("frame span %.1f us" % ((prev_end - t0) / 1e3))
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -15,7 +15,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "librt_amd.so")
 HOST_BIN = os.path.join(HERE, "bin", "raytracer")
 
-HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "lbvh.hip"]
+HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "persistent.hip", "lbvh.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the trace arithmetic must round like the reference's scalar x86 code:
@@ -40,7 +40,7 @@ def _newer(target, deps):
 
 def build_lib(force=False, verbose=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "rt_internal.h"), os.path.join(CSRC, "rt_device.h"), os.path.join(ROOT, "include", "rt_shim.h"), __file__]
+    deps = srcs + [os.path.join(CSRC, "rt_internal.h"), os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_traverse.h"), os.path.join(ROOT, "include", "rt_shim.h"), __file__]
     if not force and not extra_flags and _newer(LIB, deps):
         return LIB
     cmd = [_hipcc()] + HIP_FLAGS + list(extra_flags) + srcs + ["-o", LIB]

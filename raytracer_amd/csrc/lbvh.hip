@@ -282,7 +282,10 @@ __global__ void k_karras(const unsigned long long *__restrict__ keys, int n, int
 // the Karras hierarchy (about a quarter fewer box tests per ray on the courtyard scene).
 // Node ids as elsewhere: leaves (n-1)+sorted position, inner nodes 0..n-2 with the root = 0
 // (inner ids are handed out downward from n-2 in creation order, so the last merge is node 0).
-constexpr int PLOC_R = 16;
+#ifndef PLOC_RADIUS
+#define PLOC_RADIUS 16
+#endif
+constexpr int PLOC_R = PLOC_RADIUS;
 
 __global__ void k_ploc_init(int n, int *cid, int *size)
 {

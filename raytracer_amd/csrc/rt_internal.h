@@ -80,6 +80,8 @@ struct FrameCounters {
     unsigned long long box_tests, tri_tests, analytic_tests;
     // RT_OPT_COUNT_TESTS only: wave iterations of each traversal step and the lanes that took part
     unsigned long long node_iters, node_lanes, leaf_iters, leaf_lanes, refill_events, refill_lanes;
+    unsigned long long step_hist[16];             // rays by traversal steps taken: bin = bit length of the step count
+    unsigned int max_steps, pad_steps;
 };
 
 // ------------------------------------------------------------------ host-side state
@@ -111,7 +113,7 @@ struct FrameParams {
     int count_tests;
     int timing;
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
-    int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages
+    int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages, 3 single traversal launch
 };
 
 struct FrameWorkspace {
@@ -132,10 +134,16 @@ struct FrameWorkspace {
     int *overflow = nullptr;       // traversal stack spill columns
     size_t slots_cap = 0, overflow_cap = 0, cursors_cap = 0;
     int chunks_cap = 0, seg_cap = 0;
+    // single-launch pipeline (LBVH scenes with at most 32 lights)
+    float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
+    unsigned int *p_occ = nullptr; // [levels][pixels] occlusion bit per light
+    float4 *ls_o = nullptr, *ls_d = nullptr;   // [waves][ls_entries] private ray stacks
+    size_t p_cap = 0, ls_cap = 0;  // elements allocated in p_hits / p_occ and in ls_o / ls_d
     // staging outputs for the host-buffer entry point
     uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr;
     size_t out_cap = 0;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events;        // frame start, after each traversal stage, after the final fold
+    int n_events = 0;                      // events recorded by the last frame
     std::vector<hipEvent_t> trav_events;   // begin/end pairs around the traversal launches of the last frame
     int trav_pairs = 0;
 };
@@ -151,6 +159,22 @@ size_t wavefront_regions(size_t slots);
 size_t wavefront_cursor_words(int levels, int n_chunks);
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_hit_t,
                     hipStream_t stream, int num_cus, const std::function<int()> &stamp, int *n_launches, std::string *err);
+// persistent.hip: the LBVH pipeline with one traversal launch per frame (writes the outputs itself).
+int persistent_max_lights(void);
+int persistent_grid(int num_cus);
+size_t persistent_stack_entries(int n_lights);
+size_t persistent_overflow_ints(int num_cus);
+size_t persistent_cursor_words(void);
+int persistent_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
+                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
+                     const std::function<int()> &stamp, int *n_launches, std::string *err);
+// Which LBVH pipeline a frame uses: 1 fused, 2 staged, 3 single launch.
+inline int lbvh_pipeline(int option, int n_lights)
+{
+    if (option == 1) return 1;
+    if (option == 3 && n_lights <= 32) return 3;      // the single-launch pipeline keeps one occlusion word per hit
+    return 2;
+}
 int device_num_cus(std::string *err);   // trace.hip: CU count of the current device (cached), < 0 on error
 int trace_deinterleave(const void *src, void *dst, int W, int H, int band_rows, int n_parts, int rows_per_part,
                        int bpp, hipStream_t stream);

@@ -93,7 +93,7 @@ void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
                      ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.hits, ws.occ, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
-                     ws.sq_counts, ws.trace_cursors, ws.overflow };
+                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -101,8 +101,9 @@ void free_workspace(FrameWorkspace &ws)
     ws = FrameWorkspace();
 }
 
-int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, bool wavefront, bool host_outputs)
+int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pipe, bool host_outputs)
 {
+    const bool wavefront = pipe == 2;
     FrameWorkspace &ws = c->ws;
     if (!ws.counters) {
         if (hipMalloc((void **)&ws.counters, sizeof(FrameCounters)) != hipSuccess)
@@ -164,6 +165,47 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, bool wa
             ws.cursors_cap = ctr;
         }
         const size_t ovf = wavefront_overflow_ints(cus);
+        if (ovf > ws.overflow_cap) {
+            if (ws.overflow) (void)hipFree(ws.overflow);
+            ws.overflow = nullptr; ws.overflow_cap = 0;
+            if (hipMalloc((void **)&ws.overflow, sizeof(int) * ovf) != hipSuccess)
+                return fail(RT_E_NOMEM, "hipMalloc(stack overflow columns) failed");
+            ws.overflow_cap = ovf;
+        }
+    }
+    if (pipe == 3) {
+        std::string err;
+        const int cus = device_num_cus(&err);
+        if (cus <= 0) return fail(RT_E_DEVICE, err);
+        const size_t need = pixels * (size_t)levels;
+        if (need > ws.p_cap) {
+            if (ws.p_hits) (void)hipFree(ws.p_hits);
+            if (ws.p_occ) (void)hipFree(ws.p_occ);
+            ws.p_hits = nullptr; ws.p_occ = nullptr; ws.p_cap = 0;
+            hipError_t e = hipMalloc((void **)&ws.p_hits, sizeof(float2) * need);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.p_occ, sizeof(unsigned int) * need);
+            if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("hit planes: ") + hipGetErrorString(e));
+            ws.p_cap = need;
+        }
+        const size_t ls = persistent_stack_entries(c->n_lights) * (size_t)persistent_grid(cus) * 4;
+        if (ls > ws.ls_cap) {
+            if (ws.ls_o) (void)hipFree(ws.ls_o);
+            if (ws.ls_d) (void)hipFree(ws.ls_d);
+            ws.ls_o = ws.ls_d = nullptr; ws.ls_cap = 0;
+            hipError_t e = hipMalloc((void **)&ws.ls_o, sizeof(float4) * ls);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.ls_d, sizeof(float4) * ls);
+            if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("private ray stacks: ") + hipGetErrorString(e));
+            ws.ls_cap = ls;
+        }
+        const size_t ctr = persistent_cursor_words();
+        if (ctr > ws.cursors_cap) {
+            if (ws.trace_cursors) (void)hipFree(ws.trace_cursors);
+            ws.trace_cursors = nullptr; ws.cursors_cap = 0;
+            if (hipMalloc((void **)&ws.trace_cursors, sizeof(unsigned int) * ctr) != hipSuccess)
+                return fail(RT_E_NOMEM, "hipMalloc(claim cursors) failed");
+            ws.cursors_cap = ctr;
+        }
+        const size_t ovf = persistent_overflow_ints(cus);
         if (ovf > ws.overflow_cap) {
             if (ws.overflow) (void)hipFree(ws.overflow);
             ws.overflow = nullptr; ws.overflow_cap = 0;
@@ -241,9 +283,10 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     if (pixels == 0) return RT_OK;
     int accel = 0;
     if (int rc = ensure_accel(c, &accel)) return rc;
-    const bool wavefront = accel == 1 && c->opt_pipeline != 1;
+    const int pipe = accel == 1 ? lbvh_pipeline(c->opt_pipeline, c->n_lights) : 1;
+    const bool wavefront = pipe != 1;
     const size_t slots = (size_t)((W + 7) / 8) * (size_t)((rows->n_rows + 7) / 8) * 64;
-    if (int rc = ensure_workspace(c, pixels, slots, max_depth + 1, wavefront, host_outputs)) return rc;
+    if (int rc = ensure_workspace(c, pixels, slots, max_depth + 1, pipe, host_outputs)) return rc;
 
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
@@ -335,7 +378,7 @@ int rt_set_option(rt_ctx *c, int option, int value)
         c->opt_builder = value;
         return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0..3");
         c->opt_pipeline = value;
         return RT_OK;
     default: return fail(RT_E_INVALID, "unknown option");
@@ -582,19 +625,20 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
                 fc.node_iters, (double)fc.node_lanes / (double)fc.node_iters, fc.leaf_iters,
                 fc.leaf_iters ? (double)fc.leaf_lanes / (double)fc.leaf_iters : 0.0, fc.refill_events,
                 fc.refill_events ? (double)fc.refill_lanes / (double)fc.refill_events : 0.0);
+    if (c->opt_count && getenv("RT_WF_DEBUG") && fc.max_steps) {
+        fprintf(stderr, "[rt] steps per ray: max %u; rays by bit length of the step count:", fc.max_steps);
+        for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", fc.step_hist[k]);
+        fprintf(stderr, "\n");
+    }
     out->n_launches = c->last_launches;
     out->accel = c->last_accel;
-    if (c->opt_timing && (int)c->ws.events.size() >= c->last_levels + 2) {
-        // events: [start] (bounce level k) x levels [after each] (resolve) [end]
-        float ms = 0.f, tr = 0.f;
-        for (int k = 0; k < c->last_levels; k++) {
-            if (hipEventElapsedTime(&ms, c->ws.events[(size_t)k], c->ws.events[(size_t)k + 1]) == hipSuccess) tr += ms;
-        }
-        out->ms_trace = tr;
-        if (hipEventElapsedTime(&ms, c->ws.events[(size_t)c->last_levels], c->ws.events[(size_t)c->last_levels + 1]) == hipSuccess)
-            out->ms_resolve = ms;
-        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)c->last_levels + 1]) == hipSuccess)
-            out->ms_frame = ms;
+    const int ne = c->ws.n_events;
+    if (c->opt_timing && ne >= 3 && (int)c->ws.events.size() >= ne) {
+        // events: [start] [after each traversal stage] ... [after the final fold]
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)ne - 2]) == hipSuccess) out->ms_trace = ms;
+        if (hipEventElapsedTime(&ms, c->ws.events[(size_t)ne - 2], c->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_resolve = ms;
+        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_frame = ms;
         out->ms_traverse = out->ms_trace;
         if (c->last_wavefront && c->ws.trav_pairs > 0 && (int)c->ws.trav_events.size() >= 2 * c->ws.trav_pairs) {
             float tv = 0.f;

@@ -455,7 +455,16 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     int launches = 0;
     const int full_grid = g_num_cus * 8;
     if (int rc = stamp()) return rc;
-    const bool wavefront = scene.accel == 1 && fp.pipeline != 1;
+    const int pipe = scene.accel == 1 ? lbvh_pipeline(fp.pipeline, scene.n_lights) : 1;
+    const bool wavefront = pipe == 2;
+    if (pipe == 3) {
+        std::function<int()> st = stamp;
+        if (int rc = persistent_frame(scene, cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, g_num_cus, st, &launches, err))
+            return rc;
+        ws.n_events = (int)ev;
+        if (n_launches) *n_launches = launches;
+        return RT_OK;
+    }
     if (wavefront) {
         std::function<int()> st = stamp;
         if (int rc = wavefront_frame(scene, cam, fp, ws, d_hit_t, stream, g_num_cus, st, &launches, err)) return rc;
@@ -493,6 +502,7 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     launches++;
     if (int rc = stamp()) return rc;
     RT_HIP_CHECK(hipGetLastError(), err);
+    ws.n_events = (int)ev;
     if (n_launches) *n_launches = launches;
     return RT_OK;
 }

@@ -28,7 +28,7 @@
 // body executes per iteration and at least half of the busy lanes advance.
 // The per-lane traversal stack lives in LDS (16 entries, column-per-lane: conflict-free)
 // and overflows to a global column for the rare deeper path.
-#include "rt_device.h"
+#include "rt_traverse.h"
 
 #include <stdlib.h>
 
@@ -74,11 +74,6 @@ constexpr int SHARDS = 64;                // claim cursors per launch
 constexpr int CURSOR_STRIDE = 32;         // words between cursors: each on its own 128-byte line, because atomics
                                           // to one line serialise (~90 per microsecond) wherever in the line they land
 constexpr int MAX_PROBES = 8;             // shards a wave tries (its own first) before it stops claiming
-// v_perm_b32 selectors that lift one 16-bit half of a packed plane pair into float bits
-// 0x3f000000 | half << 8 (bit 15 of every stored half is set, so this is 1 + q/32768): byte 3 from the
-// constant operand, bytes 2-1 from the half, byte 0 zero.
-constexpr unsigned int SEL_LO = 0x0401000cu, SEL_HI = 0x0403020cu, PERM_EXP = 0x3f3f3f3fu;
-constexpr float INV_MAX = 1e30f;          // stands in for 1/0 so that lo*inv - o*inv stays finite
 
 struct TraceArgs {
     DevScene sc;
@@ -97,19 +92,6 @@ struct TraceArgs {
     unsigned int total_lanes;
     FrameCounters *counters;
 };
-
-typedef float V2 __attribute__((ext_vector_type(2)));
-
-// Entry (x) and exit (y) parameter of the ray against one axis' plane pair, packed lo | hi << 16 on
-// the lattice: sel_n / sel_f pick the half the ray meets first / last, and t = f*s + b with
-// f = 1 + q/32768 read straight from the permuted bits.
-__device__ __forceinline__ V2 plane_pair(unsigned int w, unsigned int sel_n, unsigned int sel_f, float s, float b)
-{
-    const V2 f = { __uint_as_float(__builtin_amdgcn_perm(PERM_EXP, w, sel_n)),
-                   __uint_as_float(__builtin_amdgcn_perm(PERM_EXP, w, sel_f)) };
-    const V2 sv = { s, s }, bv = { b, b };
-    return __builtin_elementwise_fma(f, sv, bv);
-}
 
 template <bool ANYHIT, bool PRIMARY, bool COUNT>
 __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)

@@ -337,15 +337,36 @@ def test_light_counts_across_the_32_light_chunks(n_lights):
     assert rays(g["stats"]) == orays(r)
 
 
-def test_fused_and_staged_pipelines_agree_bit_for_bit():
+def test_fused_staged_and_single_launch_pipelines_agree_bit_for_bit():
     spec = atrium_spec(detail=0.02)
     cam = rt.camera_for_width(320)
-    outs = []
-    for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT):
+    outs, stats = [], []
+    for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_PERSISTENT):
         with rt.Context(0) as ctx:
             ctx.set_option(rt.OPT_PIPELINE, pipeline)
             to_product(ctx, spec)
             ctx.set_camera(cam)
             outs.append(ctx.render_frame(320, 180, max_depth=4))
-    for k in ("rgb8", "hit_id", "rgb32"):
-        assert np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8)), k
+            stats.append(ctx.stats())
+    for other in outs[1:]:
+        for k in ("rgb8", "hit_id", "rgb32", "hit_t"):
+            if k in outs[0] and outs[0][k] is not None:
+                assert np.array_equal(outs[0][k].view(np.uint8), other[k].view(np.uint8)), k
+    for st in stats[1:]:
+        assert (st["rays_shadow"], st["rays_reflect"]) == (stats[0]["rays_shadow"], stats[0]["rays_reflect"])
+    assert stats[2]["n_launches"] == 2 and stats[1]["n_launches"] > 10
+
+
+def test_single_launch_pipeline_matches_the_oracle_on_golden_scenes():
+    for name, (spec, W, H, bounces, cam) in golden_cases().items():
+        if spec.n_tris < 2:
+            continue
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+            ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_PERSISTENT)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            g = ctx.render_frame(W, H, max_depth=bounces)
+            g["stats"] = ctx.stats()
+        r = to_oracle(spec).render(W, H, max_depth=bounces, cam=ocam(cam))
+        assert_parity(compare(g, r)), name
