@@ -125,7 +125,7 @@ struct FrameWorkspace {
     size_t pixels_cap = 0;
     int levels_cap = 0;
     // wavefront pipeline (LBVH scenes)
-    float2 *hits = nullptr;        // [slots_cap] nearest (t, id bits) of the current level
+    float2 *hits = nullptr;        // [2][slots_cap] nearest (t, id bits), one plane per level parity
     unsigned int *occ = nullptr;   // [chunks_cap][slots_cap] shadow bits, 32 lights per word
     float4 *sq_o = nullptr, *sq_d = nullptr;   // [seg_cap][slots_cap] shadow rays, one segment per light of a chunk
     unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue

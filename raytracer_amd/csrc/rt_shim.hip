@@ -146,7 +146,7 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             const int cc = n_chunks > ws.chunks_cap ? n_chunks : ws.chunks_cap, gc = segs > ws.seg_cap ? segs : ws.seg_cap;
             const size_t regions = wavefront_regions(sc);
             ws.slots_cap = 0; ws.chunks_cap = 0; ws.seg_cap = 0;
-            hipError_t e = hipMalloc((void **)&ws.hits, sizeof(float2) * sc);
+            hipError_t e = hipMalloc((void **)&ws.hits, sizeof(float2) * sc * 2);   // one plane per level parity
             if (e == hipSuccess) e = hipMalloc((void **)&ws.occ, sizeof(unsigned int) * sc * (size_t)(cc ? cc : 1));
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_o, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_d, sizeof(float4) * sc * (size_t)(gc ? gc : 1));

@@ -55,13 +55,14 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_LEAF_MIN
 #define WF_LEAF_MIN 0
 #endif
+#ifndef WF_MERGE
+#define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
+#endif
 #ifndef WF_WAVES_EU
 #define WF_WAVES_EU 8      // > 0: register budget for this many k_trace waves per SIMD (8 = the persistent grid's residency)
 #endif
-#if WF_WAVES_EU
-#define WF_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(WF_WAVES_EU, WF_WAVES_EU)))
-#else
-#define WF_TRACE_ATTR
+#ifndef WF_WAVES_EU_MIXED
+#define WF_WAVES_EU_MIXED 7   // the mixed-kind kernel carries more state: 7 waves avoid spills in its loop
 #endif
 #ifndef WF_VOTE
 #define WF_VOTE 1
@@ -80,10 +81,12 @@ struct TraceArgs {
     DevCamera cam;
     int W, n_rows;
     rt_rowset rows;
-    const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit: shadow queue (segment-major)
+    const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit and mixed: shadow queue (segment-major)
+    const float4 *q2_o, *q2_d;      // mixed: the next level's ray queue, traced for the nearest hit
     float2 *hits;                   // closest: (t, id bits) per slot
     unsigned int *occ;              // any-hit: occ[slot] |= 1 << bit
     const unsigned int *counts;     // [segment][region] rays per region (null at level 0: regions are full)
+    const unsigned int *counts2;    // mixed: [region] rays per region of q2
     unsigned int *cursors;          // [SHARDS * CURSOR_STRIDE] unit claim cursors of this launch (zeroed per frame)
     unsigned int n_slots;           // level 0: slot count known on the host
     int n_segments, n_regions;
@@ -93,9 +96,17 @@ struct TraceArgs {
     FrameCounters *counters;
 };
 
-template <bool ANYHIT, bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
+// MODE 0: nearest hit of every ray of one queue (or of the camera rays, PRIMARY).
+// MODE 1: any-hit of the shadow rays of n_segments light segments.
+// MODE 2: both in one launch — the shadow rays of level k and the nearest-hit rays of level k+1 do
+//         not depend on each other, and one launch has one drain instead of two.  A lane's kind is
+//         the sign of `bit` (>= 0: shadow ray of that light).
+template <int MODE, bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(BLOCK)
+__attribute__((amdgpu_waves_per_eu(MODE == 2 ? WF_WAVES_EU_MIXED : WF_WAVES_EU, MODE == 2 ? WF_WAVES_EU_MIXED : WF_WAVES_EU)))
+void k_trace(TraceArgs A)
 {
+    constexpr bool ANYHIT = MODE == 1;
     __shared__ int s_stack[WF_LDS_STACK * BLOCK];
     const int lane = threadIdx.x & 63;
     int *stack = s_stack + threadIdx.x;                                   // element k at stack[k * BLOCK]
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
     const unsigned long long lt = lanemask_lt();
 
     // ---- per-lane ray state
-    int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = 0;
+    int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = MODE == 0 ? -1 : 0;
     unsigned int slot = 0;
     F3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f), oi = mk(0.f, 0.f, 0.f);
     uint3 sel_n = make_uint3(SEL_LO, SEL_LO, SEL_LO), sel_f = make_uint3(SEL_HI, SEL_HI, SEL_HI);
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
     const int n_shards = (int)min((unsigned)SHARDS, gridDim.x);
     const int max_probes = min(MAX_PROBES, n_shards);
     int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
-    const unsigned int n_units = (unsigned)A.n_segments * (unsigned)A.n_regions * UPR;
+    const unsigned int n_units = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0)) * (unsigned)A.n_regions * UPR;
     bool exhausted = n_units == 0;
 
     auto push = [&](int v) {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
             asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
             node = v;
         }
-        if (node == NODE_SENTINEL && !ANYHIT) A.hits[slot] = make_float2(best_t, __int_as_float(best_id));
+        if (node == NODE_SENTINEL && (MODE == 0 || (MODE == 2 && bit < 0))) A.hits[slot] = make_float2(best_t, __int_as_float(best_id));
     };
 
     for (;;) {
@@ -168,6 +179,8 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
                 if (PRIMARY) {
                     const unsigned int r0 = region * REGION;
                     cnt = A.n_slots > r0 ? min((unsigned)REGION, A.n_slots - r0) : 0u;
+                } else if (MODE == 2 && seg == A.n_segments) {
+                    cnt = A.counts2[region];
                 } else {
                     cnt = A.counts[(size_t)seg * A.n_regions + region];
                 }
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
             if (COUNT) { dbg[4]++; dbg[5] += min((unsigned)__popcll(idle), end - cur); }
             if (node == NODE_SENTINEL && my < end) {
                 bool live = true;
-                if (ANYHIT) {
+                const bool unit_any = MODE == 1 || (MODE == 2 && seg < A.n_segments);     // wave-uniform
+                if (unit_any) {
                     const size_t q = (size_t)seg * A.seg_stride + my;
                     const float4 qo = A.q_o[q], qd = A.q_d[q];
                     o = f3(qo); d = f3(qd);
@@ -190,13 +204,14 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
                     o = pr.o; d = pr.d; live = pr.live;
                     slot = my;
                 } else {
-                    const float4 qo = A.q_o[my], qd = A.q_d[my];
+                    const float4 qo = (MODE == 2 ? A.q2_o : A.q_o)[my], qd = (MODE == 2 ? A.q2_d : A.q_d)[my];
                     o = f3(qo); d = f3(qd);
                     slot = my;
+                    if (MODE == 2) bit = -1;
                 }
                 if (live) {
                     best_t = FLT_MAX; best_id = -1;
-                    if (!ANYHIT) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+                    if (!unit_any) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
                     // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf
                     inv = mk(fminf(fmaxf(1.0f / d.x, -INV_MAX), INV_MAX), fminf(fmaxf(1.0f / d.y, -INV_MAX), INV_MAX),
                              fminf(fmaxf(1.0f / d.z, -INV_MAX), INV_MAX));
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
                 const BvhNodeQ *np = sc.qnodes + node;
                 const uint4 qa = np->a, qb = np->b;
                 const int2 ch = make_int2((int)qb.z, (int)qb.w);
-                const float tmax = ANYHIT ? FLT_MAX : best_t;
+                const float tmax = ANYHIT ? FLT_MAX : best_t;      // mixed: a shadow lane's best_t stays FLT_MAX
                 // one fma per box plane; the lattice boxes contain the padded float boxes.  The ray's
                 // direction signs decide which plane of each pair is entered first, so no min/max per axis;
                 // one v_perm_b32 per plane builds its float, and the two planes of a pair share a packed fma.
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) WF_TRACE_ATTR void k_trace(TraceArgs A)
                 if (COUNT) tl.tri += 1;
                 tri_i++;
                 tri_left--;
-                if (ANYHIT) {
+                if (MODE == 1 || (MODE == 2 && bit >= 0)) {
                     if (h) {                                       // main.cpp:183-186: any hit blocks the light
                         atomicOr(&A.occ[slot], 1u << bit);
                         node = NODE_SENTINEL;
@@ -399,9 +414,12 @@ template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
 {
     __shared__ unsigned int s_cnt[BLOCK / 64];
+    __shared__ unsigned int s_reflect;
     const DevScene &sc = A.sc;
     Tally tl = { 0u, 0u, 0u };
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
+    if (threadIdx.x == 0) s_reflect = 0;
+    unsigned int n_reflect = 0;
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
         const unsigned int cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
@@ -409,6 +427,26 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
         bool lit = r.live && r.id >= 0;
         if (lit && r.id < sc.n_analytic && sc.analytic[r.id].is_light) lit = false;       // main.cpp:166
         const F3 pos = add(r.o, muls(r.d, r.t));                                          // main.cpp:163
+        if (A.chunk == 0) {
+            // the next level's ray (main.cpp:208-211) leaves here, before the shadow rays are traced:
+            // it does not depend on them, and the two kinds of ray share the next traversal launch
+            bool spawn = false;
+            F3 R = r.d;
+            if (lit && A.level < A.max_depth) {
+                const Surface s = surface_at(sc, r.id, pos);                              // main.cpp:164
+                spawn = s.kr > 0.0f;                                                      // main.cpp:208
+                if (spawn) R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));            // main.cpp:210
+            }
+            unsigned int total;
+            const unsigned int rank = block_rank(spawn, s_cnt, total);
+            if (spawn) {
+                const size_t dst = (size_t)region * REGION + rank;
+                A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
+                A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
+                n_reflect++;
+            }
+            if (threadIdx.x == 0) A.out_counts[region] = total;
+        }
         unsigned int bits = 0;
         for (int li = l0; li < l1; li++) {                                                // main.cpp:170-173
             const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
@@ -429,18 +467,26 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             }
             if (threadIdx.x == 0) A.sq_counts[(size_t)(li - l0) * A.n_regions + region] = total;
         }
-        if (r.live) A.occ[(size_t)A.chunk * A.slots_cap + slot] = bits;
+        if (r.live && l1 > l0) A.occ[(size_t)A.chunk * A.slots_cap + slot] = bits;
+    }
+    if (A.chunk == 0) {
+        for (int off = 32; off > 0; off >>= 1) n_reflect += __shfl_xor(n_reflect, off);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && n_reflect) atomicAdd(&s_reflect, n_reflect);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_reflect) atomicAdd(&A.counters->rays_reflect, (unsigned long long)s_reflect);
     }
 }
 
 template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shade(ShadeArgs A)
 {
-    __shared__ unsigned int s_cnt[BLOCK / 64];
     __shared__ unsigned int s_stat[2];
     const DevScene &sc = A.sc;
     if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
-    unsigned int n_shadow = 0, n_reflect = 0;
+    __syncthreads();
+    unsigned int n_shadow = 0;
+    const unsigned int n_reflect = 0;          // counted where the rays are spawned (k_shadow_gen)
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
         const unsigned int cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
@@ -481,17 +527,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(ShadeArgs A)
                 make_float4(col.x, col.y, col.z, __int_as_float(r.id));
             if (PRIMARY && A.hit_t) A.hit_t[r.pixel] = r.t;
         }
-        const bool spawn = lit && s.kr > 0.0f && A.level < A.max_depth;                  // main.cpp:208
-        unsigned int total;
-        const unsigned int rank = block_rank(spawn, s_cnt, total);
-        if (spawn) {
-            const F3 R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));                  // main.cpp:210
-            const size_t dst = (size_t)region * REGION + rank;
-            A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));      // origin is pos itself (main.cpp:211)
-            A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
-            n_reflect++;
-        }
-        if (threadIdx.x == 0) A.out_counts[region] = total;
     }
     // ray counters: wave reduce -> LDS -> one atomic per block and counter
     unsigned int vals[2] = { n_shadow, n_reflect };
@@ -505,11 +540,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(ShadeArgs A)
         atomicAdd(threadIdx.x == 0 ? &A.counters->rays_shadow : &A.counters->rays_reflect, (unsigned long long)s_stat[threadIdx.x]);
 }
 
-template <bool ANYHIT, bool PRIMARY>
+template <int MODE, bool PRIMARY>
 void launch_trace(const TraceArgs &a, bool count, int grid, hipStream_t stream)
 {
-    if (count) hipLaunchKernelGGL((k_trace<ANYHIT, PRIMARY, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((k_trace<ANYHIT, PRIMARY, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    if (count) hipLaunchKernelGGL((k_trace<MODE, PRIMARY, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_trace<MODE, PRIMARY, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
 }
 
 }  // namespace
@@ -585,48 +620,83 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         return RT_OK;
     };
     ws.trav_pairs = 0;
-    for (int level = 0; level <= fp.max_depth; level++) {
-        const bool primary = level == 0;
-        const float4 *qo = ws.queue_o[level & 1], *qd = ws.queue_d[level & 1];
-        const unsigned int *in_counts = ws.rq_counts[level & 1];
-        // ---- nearest hit
-        t.q_o = qo; t.q_d = qd;
-        t.occ = nullptr;
-        t.counts = in_counts;
-        t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
-        t.n_segments = 1; t.seg_stride = 0;
-        const int grid = (primary && n_regions * UPR < trace_grid * (BLOCK / 64)) ? (n_regions * UPR + 3) / 4 : trace_grid;
-        if (int rc = tstamp()) return rc;
-        if (primary) launch_trace<false, true>(t, count, grid, stream);
-        else launch_trace<false, false>(t, count, grid, stream);
-        if (int rc = tstamp()) return rc;
-        launches++;
-        // ---- shadows, 32 lights at a time
-        s.level = level;
-        s.q_o = qo; s.q_d = qd;
-        s.in_counts = in_counts;
+    // Level k's shadow rays and level k+1's nearest-hit rays are both known once k_shadow_gen(k) has
+    // run, and neither needs the other: they share one traversal launch (WF_MERGE), so a frame of D
+    // bounces has D + 2 traversal drains instead of 2 D + 2.
+    const bool merge = WF_MERGE != 0;
+    auto launch_gen = [&](int level, int chunk) {
+        s.level = level; s.chunk = chunk;
+        s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
+        s.in_counts = ws.rq_counts[level & 1];
+        s.hits = ws.hits + (size_t)(level & 1) * ws.slots_cap;
         s.nq_o = ws.queue_o[(level + 1) & 1]; s.nq_d = ws.queue_d[(level + 1) & 1];
         s.out_counts = ws.rq_counts[(level + 1) & 1];
-        for (int chunk = 0; chunk < n_chunks; chunk++) {
-            s.chunk = chunk;
-            if (primary) hipLaunchKernelGGL(k_shadow_gen<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
-            else hipLaunchKernelGGL(k_shadow_gen<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        if (level == 0) hipLaunchKernelGGL(k_shadow_gen<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        else hipLaunchKernelGGL(k_shadow_gen<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        launches++;
+    };
+    // mode 0: nearest hit of `level`; 1: shadow rays of (level, chunk); 2: shadow rays of (level, chunk) + nearest hit of level + 1
+    auto launch_traversal = [&](int mode, int level, int chunk) -> int {
+        t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
+        const int close_level = mode == 2 ? level + 1 : level;
+        t.hits = ws.hits + (size_t)(close_level & 1) * ws.slots_cap;
+        if (mode == 0) {
+            t.q_o = ws.queue_o[level & 1]; t.q_d = ws.queue_d[level & 1];
+            t.counts = ws.rq_counts[level & 1];
+            t.occ = nullptr;
+            t.n_segments = 1; t.seg_stride = 0;
+        } else {
             t.q_o = ws.sq_o; t.q_d = ws.sq_d;
-            t.occ = ws.occ + (size_t)chunk * ws.slots_cap;
             t.counts = ws.sq_counts;
-            t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
+            t.occ = ws.occ + (size_t)chunk * ws.slots_cap;
             t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;
             t.seg_stride = (unsigned)ws.slots_cap;
-            if (int rc = tstamp()) return rc;
-            launch_trace<true, false>(t, count, trace_grid, stream);
-            if (int rc = tstamp()) return rc;
-            launches += 2;
+            t.q2_o = ws.queue_o[(level + 1) & 1]; t.q2_d = ws.queue_d[(level + 1) & 1];
+            t.counts2 = ws.rq_counts[(level + 1) & 1];
         }
-        // ---- local colour, record, reflection rays
-        if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
+        const bool primary = mode == 0 && level == 0;
+        int grid = (primary && n_regions * UPR < trace_grid * (BLOCK / 64)) ? (n_regions * UPR + 3) / 4 : trace_grid;
+        if (mode == 2 && grid > num_cus * WF_WAVES_EU_MIXED) grid = num_cus * WF_WAVES_EU_MIXED;   // resident blocks only
+        if (int rc = tstamp()) return rc;
+        if (primary) launch_trace<0, true>(t, count, grid, stream);
+        else if (mode == 0) launch_trace<0, false>(t, count, grid, stream);
+        else if (mode == 1) launch_trace<1, false>(t, count, grid, stream);
+        else launch_trace<2, false>(t, count, grid, stream);
+        launches++;
+        return tstamp();
+    };
+    auto launch_shade = [&](int level) {
+        s.level = level;
+        s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
+        s.in_counts = ws.rq_counts[level & 1];
+        s.hits = ws.hits + (size_t)(level & 1) * ws.slots_cap;
+        if (level == 0) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
         else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
         launches++;
+    };
+    if (int rc = launch_traversal(0, 0, 0)) return rc;
+    for (int level = 0; level <= fp.max_depth; level++) {
+        const bool more = level < fp.max_depth;
+        // chunk 0 also spawns the next level's rays; it runs even without lights
+        launch_gen(level, 0);
+        bool next_traced = false;
+        if (n_chunks > 0) {
+            if (merge && more) {
+                if (int rc = launch_traversal(2, level, 0)) return rc;
+                next_traced = true;
+            } else {
+                if (int rc = launch_traversal(1, level, 0)) return rc;
+            }
+        }
+        for (int chunk = 1; chunk < n_chunks; chunk++) {
+            launch_gen(level, chunk);
+            if (int rc = launch_traversal(1, level, chunk)) return rc;
+        }
+        // ---- local colour and record (needs every chunk's occlusion bits)
+        launch_shade(level);
         if (int rc = stamp()) return rc;
+        if (more && !next_traced)
+            if (int rc = launch_traversal(0, level + 1, 0)) return rc;
     }
     RT_HIP_CHECK(hipGetLastError(), err);
     ws.trav_pairs = (int)(te / 2);
