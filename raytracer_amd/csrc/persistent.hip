@@ -338,8 +338,9 @@ struct ShadeAllArgs {
     DevCamera cam;
     int W, n_rows, n_pixels, max_depth;
     rt_rowset rows;
-    const float2 *hits;
-    const unsigned int *occ;
+    const float2 *hits;               // [level][pixel]
+    const unsigned int *occ;          // [level][chunk][pixel], 32 lights per chunk
+    int n_chunks;
     float4 *records;                  // [level][pixel] scratch: (local colour, hit id bits)
     uint8_t *rgb8; int32_t *hit_id; float *rgb32; float *hit_t;
     FrameCounters *counters;
@@ -383,11 +384,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
                     col = s.Mc;                                                           // main.cpp:166-167
                 } else {
                     n_shadow += (unsigned)sc.n_lights;
-                    const unsigned int bits = A.occ[(size_t)k * (size_t)A.n_pixels + p];
+                    unsigned int bits = 0;
                     for (int li = 0; li < sc.n_lights; li++) {                            // main.cpp:170-173
+                        if ((li & 31) == 0) bits = A.occ[((size_t)k * A.n_chunks + (li >> 5)) * (size_t)A.n_pixels + p];
                         const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
                         const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));     // main.cpp:178
-                        const float shade = ((bits >> li) & 1u) ? 0.0f : 1.0f;            // main.cpp:175, 185
+                        const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;     // main.cpp:175, 185
                         const F3 Lc = mk(lt_.cr, lt_.cg, lt_.cb);
                         if (s.kd > 0.0f) {                                                // main.cpp:191-195
                             const float diffuse = dot(s.N, L) * s.kd;
@@ -455,6 +457,23 @@ int blocks_per_cu()
 
 }  // namespace
 
+int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, const float2 *hits,
+                     const unsigned int *occ, int n_chunks, float4 *records, FrameCounters *counters, void *d_rgb8, void *d_hit_id,
+                     void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus, std::string *err)
+{
+    ShadeAllArgs s;
+    s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = fp.rows.n_rows; s.n_pixels = fp.W * fp.rows.n_rows; s.max_depth = fp.max_depth;
+    s.rows = fp.rows;
+    s.hits = hits; s.occ = occ; s.n_chunks = n_chunks; s.records = records;
+    s.rgb8 = (uint8_t *)d_rgb8; s.hit_id = (int32_t *)d_hit_id; s.rgb32 = (float *)d_rgb32; s.hit_t = (float *)d_hit_t;
+    s.counters = counters;
+    int sgrid = (s.n_pixels + BLOCK - 1) / BLOCK;
+    if (sgrid > num_cus * 8) sgrid = num_cus * 8;
+    hipLaunchKernelGGL(k_shade_all, dim3(sgrid), dim3(BLOCK), 0, stream, s);
+    RT_HIP_CHECK(hipGetLastError(), err);
+    return RT_OK;
+}
+
 int persistent_max_lights(void) { return 32; }
 int persistent_grid(int num_cus) { return num_cus * blocks_per_cu(); }
 // entries of one wave's private ray stack: one hit's worth of rays per lane (doubled as a margin;
@@ -513,15 +532,9 @@ int persistent_frame(const DevScene &scene, const DevCamera &cam, const FramePar
     ws.trav_pairs = (int)(te / 2);
     if (int rc = stamp()) return rc;
 
-    ShadeAllArgs s;
-    s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = n_rows; s.n_pixels = n_pixels; s.max_depth = fp.max_depth;
-    s.rows = fp.rows;
-    s.hits = ws.p_hits; s.occ = ws.p_occ; s.records = ws.records;
-    s.rgb8 = (uint8_t *)d_rgb8; s.hit_id = (int32_t *)d_hit_id; s.rgb32 = (float *)d_rgb32; s.hit_t = (float *)d_hit_t;
-    s.counters = ws.counters;
-    int sgrid = (n_pixels + BLOCK - 1) / BLOCK;
-    if (sgrid > num_cus * 8) sgrid = num_cus * 8;
-    hipLaunchKernelGGL(k_shade_all, dim3(sgrid), dim3(BLOCK), 0, stream, s);
+    if (int rc = shade_all_launch(scene, cam, fp, ws.p_hits, ws.p_occ, 1, ws.records, ws.counters, d_rgb8, d_hit_id, d_rgb32,
+                                  d_hit_t, stream, num_cus, err))
+        return rc;
     if (int rc = stamp()) return rc;
     RT_HIP_CHECK(hipGetLastError(), err);
     *n_launches += 2;

@@ -125,8 +125,6 @@ struct FrameWorkspace {
     size_t pixels_cap = 0;
     int levels_cap = 0;
     // wavefront pipeline (LBVH scenes)
-    float2 *hits = nullptr;        // [2][slots_cap] nearest (t, id bits), one plane per level parity
-    unsigned int *occ = nullptr;   // [chunks_cap][slots_cap] shadow bits, 32 lights per word
     float4 *sq_o = nullptr, *sq_d = nullptr;   // [seg_cap][slots_cap] shadow rays, one segment per light of a chunk
     unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue
     unsigned int *sq_counts = nullptr;         // [seg_cap][regions] shadow rays per segment and region
@@ -134,9 +132,10 @@ struct FrameWorkspace {
     int *overflow = nullptr;       // traversal stack spill columns
     size_t slots_cap = 0, overflow_cap = 0, cursors_cap = 0;
     int chunks_cap = 0, seg_cap = 0;
-    // single-launch pipeline (LBVH scenes with at most 32 lights)
+    // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
-    unsigned int *p_occ = nullptr; // [levels][pixels] occlusion bit per light
+    unsigned int *p_occ = nullptr; // [levels][chunks][pixels] occlusion bit per light, 32 lights per chunk
+    // single-launch pipeline (at most 32 lights)
     float4 *ls_o = nullptr, *ls_d = nullptr;   // [waves][ls_entries] private ray stacks
     size_t p_cap = 0, ls_cap = 0;  // elements allocated in p_hits / p_occ and in ls_o / ls_d
     // staging outputs for the host-buffer entry point
@@ -157,8 +156,13 @@ int wavefront_trace_grid(int num_cus);
 size_t wavefront_overflow_ints(int num_cus);
 size_t wavefront_regions(size_t slots);
 size_t wavefront_cursor_words(int levels, int n_chunks);
-int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_hit_t,
-                    hipStream_t stream, int num_cus, const std::function<int()> &stamp, int *n_launches, std::string *err);
+int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
+                    void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
+                    const std::function<int()> &stamp, int *n_launches, std::string *err);
+// persistent.hip: local colour of every level, fold and outputs from the [level][pixel] hit and occlusion planes
+int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, const float2 *hits,
+                     const unsigned int *occ, int n_chunks, float4 *records, FrameCounters *counters, void *d_rgb8, void *d_hit_id,
+                     void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus, std::string *err);
 // persistent.hip: the LBVH pipeline with one traversal launch per frame (writes the outputs itself).
 int persistent_max_lights(void);
 int persistent_grid(int num_cus);

@@ -92,7 +92,7 @@ void free_triangles(rt_ctx *c)
 void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
-                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.hits, ws.occ, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
                      ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -137,18 +137,16 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         const int cus = device_num_cus(&err);
         if (cus <= 0) return fail(RT_E_DEVICE, err);
         if (qslots > ws.slots_cap || n_chunks > ws.chunks_cap || segs > ws.seg_cap) {
-            void *old[] = { ws.hits, ws.occ, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1], ws.sq_counts };
+            void *old[] = { ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1], ws.sq_counts };
             for (void *p : old)
                 if (p) (void)hipFree(p);
-            ws.hits = nullptr; ws.occ = nullptr; ws.sq_o = ws.sq_d = nullptr;
+            ws.sq_o = ws.sq_d = nullptr;
             ws.rq_counts[0] = ws.rq_counts[1] = ws.sq_counts = nullptr;
             const size_t sc = qslots > ws.slots_cap ? qslots : ws.slots_cap;
             const int cc = n_chunks > ws.chunks_cap ? n_chunks : ws.chunks_cap, gc = segs > ws.seg_cap ? segs : ws.seg_cap;
             const size_t regions = wavefront_regions(sc);
             ws.slots_cap = 0; ws.chunks_cap = 0; ws.seg_cap = 0;
-            hipError_t e = hipMalloc((void **)&ws.hits, sizeof(float2) * sc * 2);   // one plane per level parity
-            if (e == hipSuccess) e = hipMalloc((void **)&ws.occ, sizeof(unsigned int) * sc * (size_t)(cc ? cc : 1));
-            if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_o, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
+            hipError_t e = hipMalloc((void **)&ws.sq_o, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_d, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
             if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[0], sizeof(unsigned int) * regions);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[1], sizeof(unsigned int) * regions);
@@ -173,20 +171,25 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             ws.overflow_cap = ovf;
         }
     }
-    if (pipe == 3) {
-        std::string err;
-        const int cus = device_num_cus(&err);
-        if (cus <= 0) return fail(RT_E_DEVICE, err);
-        const size_t need = pixels * (size_t)levels;
+    if (pipe == 2 || pipe == 3) {
+        // [level][pixel] hits and [level][chunk][pixel] occlusion words
+        const size_t n_chunks = (size_t)((c->n_lights + 31) / 32 > 0 ? (c->n_lights + 31) / 32 : 1);
+        const size_t need = pixels * (size_t)levels * n_chunks;
         if (need > ws.p_cap) {
             if (ws.p_hits) (void)hipFree(ws.p_hits);
             if (ws.p_occ) (void)hipFree(ws.p_occ);
             ws.p_hits = nullptr; ws.p_occ = nullptr; ws.p_cap = 0;
+            // both planes get `need` elements so that one capacity covers any later (levels, chunks) split
             hipError_t e = hipMalloc((void **)&ws.p_hits, sizeof(float2) * need);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.p_occ, sizeof(unsigned int) * need);
             if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("hit planes: ") + hipGetErrorString(e));
             ws.p_cap = need;
         }
+    }
+    if (pipe == 3) {
+        std::string err;
+        const int cus = device_num_cus(&err);
+        if (cus <= 0) return fail(RT_E_DEVICE, err);
         const size_t ls = persistent_stack_entries(c->n_lights) * (size_t)persistent_grid(cus) * 4;
         if (ls > ws.ls_cap) {
             if (ws.ls_o) (void)hipFree(ws.ls_o);

@@ -467,7 +467,11 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     }
     if (wavefront) {
         std::function<int()> st = stamp;
-        if (int rc = wavefront_frame(scene, cam, fp, ws, d_hit_t, stream, g_num_cus, st, &launches, err)) return rc;
+        if (int rc = wavefront_frame(scene, cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, g_num_cus, st, &launches, err))
+            return rc;
+        ws.n_events = (int)ev;
+        if (n_launches) *n_launches = launches;
+        return RT_OK;
     }
     for (int level = 0; level <= fp.max_depth && !wavefront; level++) {
         a.level = level;

@@ -83,8 +83,8 @@ struct TraceArgs {
     rt_rowset rows;
     const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit and mixed: shadow queue (segment-major)
     const float4 *q2_o, *q2_d;      // mixed: the next level's ray queue, traced for the nearest hit
-    float2 *hits;                   // closest: (t, id bits) per slot
-    unsigned int *occ;              // any-hit: occ[slot] |= 1 << bit
+    float2 *hits;                   // nearest hit: (t, id bits) per PIXEL, the plane of the level being traced
+    unsigned int *occ;              // any-hit: occ[pixel] |= 1 << bit, the plane of (level, light chunk)
     const unsigned int *counts;     // [segment][region] rays per region (null at level 0: regions are full)
     const unsigned int *counts2;    // mixed: [region] rays per region of q2
     unsigned int *cursors;          // [SHARDS * CURSOR_STRIDE] unit claim cursors of this launch (zeroed per frame)
@@ -116,7 +116,7 @@ void k_trace(TraceArgs A)
 
     // ---- per-lane ray state
     int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = MODE == 0 ? -1 : 0;
-    unsigned int slot = 0;
+    unsigned int slot = 0;             // the ray's pixel: index into the hit / occlusion plane
     F3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f), oi = mk(0.f, 0.f, 0.f);
     uint3 sel_n = make_uint3(SEL_LO, SEL_LO, SEL_LO), sel_f = make_uint3(SEL_HI, SEL_HI, SEL_HI);
     float best_t = FLT_MAX;
@@ -202,11 +202,11 @@ void k_trace(TraceArgs A)
                 } else if (PRIMARY) {
                     const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, my);
                     o = pr.o; d = pr.d; live = pr.live;
-                    slot = my;
+                    slot = (unsigned)pr.pixel;
                 } else {
                     const float4 qo = (MODE == 2 ? A.q2_o : A.q_o)[my], qd = (MODE == 2 ? A.q2_d : A.q_d)[my];
                     o = f3(qo); d = f3(qd);
-                    slot = my;
+                    slot = (unsigned)__float_as_int(qo.w);
                     if (MODE == 2) bit = -1;
                 }
                 if (live) {
@@ -339,17 +339,14 @@ struct ShadeArgs {
     int n_regions;
     const unsigned int *in_counts;    // level > 0: rays per region of this level's queue
     const float4 *q_o, *q_d;          // this level's rays
-    const float2 *hits;
-    unsigned int *occ;                // [chunk][slots_cap]
+    const float2 *hits;               // [pixel] nearest hits of this level
+    unsigned int *occ;                // [pixel] occlusion bits of (this level, this chunk)
     unsigned int slots_cap;
     // k_shadow_gen
     int chunk;
     float4 *sq_o, *sq_d;              // [segment][slots_cap]
     unsigned int *sq_counts;          // [segment][region]
-    // k_shade
-    float4 *records;
-    float *hit_t;
-    float4 *nq_o, *nq_d;
+    float4 *nq_o, *nq_d;              // next level's rays
     unsigned int *out_counts;         // next level's rays per region
     FrameCounters *counters;
 };
@@ -383,7 +380,7 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
         }
     }
     if (r.live) {
-        const float2 h = A.hits[slot];
+        const float2 h = A.hits[r.pixel];
         r.t = h.x; r.id = __float_as_int(h.y);
         // never index scene arrays with an id outside the scene
         if (r.id >= A.sc.n_analytic + A.sc.n_tris) r.id = -1;
@@ -414,12 +411,9 @@ template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
 {
     __shared__ unsigned int s_cnt[BLOCK / 64];
-    __shared__ unsigned int s_reflect;
     const DevScene &sc = A.sc;
     Tally tl = { 0u, 0u, 0u };
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
-    if (threadIdx.x == 0) s_reflect = 0;
-    unsigned int n_reflect = 0;
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
         const unsigned int cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
@@ -443,7 +437,6 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
                 const size_t dst = (size_t)region * REGION + rank;
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
                 A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
-                n_reflect++;
             }
             if (threadIdx.x == 0) A.out_counts[region] = total;
         }
@@ -462,82 +455,13 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             const unsigned int rank = block_rank(want, s_cnt, total);
             if (want) {
                 const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)region * REGION + rank;
-                A.sq_o[q] = make_float4(so.x, so.y, so.z, __int_as_float((int)slot));
+                A.sq_o[q] = make_float4(so.x, so.y, so.z, __int_as_float(r.pixel));
                 A.sq_d[q] = make_float4(L.x, L.y, L.z, __int_as_float(li - l0));
             }
             if (threadIdx.x == 0) A.sq_counts[(size_t)(li - l0) * A.n_regions + region] = total;
         }
-        if (r.live && l1 > l0) A.occ[(size_t)A.chunk * A.slots_cap + slot] = bits;
+        if (r.live && l1 > l0) A.occ[r.pixel] = bits;
     }
-    if (A.chunk == 0) {
-        for (int off = 32; off > 0; off >>= 1) n_reflect += __shfl_xor(n_reflect, off);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0 && n_reflect) atomicAdd(&s_reflect, n_reflect);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_reflect) atomicAdd(&A.counters->rays_reflect, (unsigned long long)s_reflect);
-    }
-}
-
-template <bool PRIMARY>
-__global__ __launch_bounds__(BLOCK) void k_shade(ShadeArgs A)
-{
-    __shared__ unsigned int s_stat[2];
-    const DevScene &sc = A.sc;
-    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
-    __syncthreads();
-    unsigned int n_shadow = 0;
-    const unsigned int n_reflect = 0;          // counted where the rays are spawned (k_shadow_gen)
-    for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
-        const unsigned int cnt = region_count<PRIMARY>(A, region);
-        const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
-        const SlotRay r = load_slot<PRIMARY>(A, slot, threadIdx.x < cnt);
-        const bool hit = r.live && r.id >= 0;
-        F3 col = mk(0.f, 0.f, 0.f), pos = mk(0.f, 0.f, 0.f);
-        Surface s;
-        s.N = mk(0.f, 0.f, 1.f); s.Mc = mk(0.f, 0.f, 0.f); s.kr = s.kd = s.ks = 0.f; s.emissive = false;
-        if (hit) {
-            pos = add(r.o, muls(r.d, r.t));                                               // main.cpp:163
-            s = surface_at(sc, r.id, pos);                                                // main.cpp:164
-        }
-        const bool lit = hit && !s.emissive;
-        if (hit && s.emissive) col = s.Mc;                                                // main.cpp:166-167
-        if (lit) {
-            n_shadow += (unsigned)sc.n_lights;
-            unsigned int bits = 0;
-            for (int li = 0; li < sc.n_lights; li++) {                                    // main.cpp:170-173
-                if ((li & 31) == 0) bits = A.occ[(size_t)(li >> 5) * A.slots_cap + slot];
-                const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
-                const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));             // main.cpp:178
-                const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;             // main.cpp:175, 185
-                const F3 Lc = mk(lt_.cr, lt_.cg, lt_.cb);
-                if (s.kd > 0.0f) {                                                        // main.cpp:191-195
-                    float diffuse = dot(s.N, L) * s.kd;
-                    col = add(col, muls(muls(mulv(Lc, s.Mc), diffuse), shade));
-                }
-                if (s.ks > 0.0f) {                                                        // main.cpp:198-204
-                    F3 R = sub(L, muls(muls(s.N, dot(L, s.N)), 2.0f));
-                    float dt = dot(r.d, R);
-                    if (dt > 0.0f)
-                        col = add(col, muls(muls(muls(mulv(Lc, s.Mc), pow20(dt)), s.ks), shade));
-                }
-            }
-        }
-        if (r.live) {
-            A.records[(size_t)A.level * (size_t)A.n_pixels + (size_t)r.pixel] =
-                make_float4(col.x, col.y, col.z, __int_as_float(r.id));
-            if (PRIMARY && A.hit_t) A.hit_t[r.pixel] = r.t;
-        }
-    }
-    // ray counters: wave reduce -> LDS -> one atomic per block and counter
-    unsigned int vals[2] = { n_shadow, n_reflect };
-    for (int k = 0; k < 2; k++) {
-        unsigned int v = vals[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[k], v);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_stat[threadIdx.x])
-        atomicAdd(threadIdx.x == 0 ? &A.counters->rays_shadow : &A.counters->rays_reflect, (unsigned long long)s_stat[threadIdx.x]);
 }
 
 template <int MODE, bool PRIMARY>
@@ -569,8 +493,9 @@ size_t wavefront_cursor_words(int levels, int n_chunks)
     return (size_t)SHARDS * CURSOR_STRIDE * (size_t)levels * (size_t)(1 + n_chunks);
 }
 
-int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_hit_t,
-                    hipStream_t stream, int num_cus, const std::function<int()> &stamp, int *n_launches, std::string *err)
+int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
+                    void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
+                    const std::function<int()> &stamp, int *n_launches, std::string *err)
 {
     const int n_rows = fp.rows.n_rows;
     const int n_pixels = fp.W * n_rows;
@@ -589,7 +514,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
 
     TraceArgs t;
     t.sc = scene; t.cam = cam; t.W = fp.W; t.n_rows = n_rows; t.rows = fp.rows;
-    t.hits = ws.hits;
+    t.hits = ws.p_hits;
     t.n_slots = n_slots; t.n_regions = n_regions;
     t.overflow = ws.overflow; t.total_lanes = (unsigned)trace_grid * BLOCK;
     t.counters = ws.counters;
@@ -598,11 +523,15 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = n_rows; s.n_pixels = n_pixels; s.rows = fp.rows;
     s.max_depth = fp.max_depth;
     s.n_slots = n_slots; s.n_regions = n_regions;
-    s.hits = ws.hits;
-    s.occ = ws.occ; s.slots_cap = (unsigned)ws.slots_cap;
+    s.hits = ws.p_hits;
+    s.occ = ws.p_occ; s.slots_cap = (unsigned)ws.slots_cap;
     s.sq_o = ws.sq_o; s.sq_d = ws.sq_d; s.sq_counts = ws.sq_counts;
-    s.records = ws.records; s.hit_t = (float *)d_hit_t;
     s.counters = ws.counters;
+    // hit and occlusion planes are indexed [level][pixel] and [level][chunk][pixel]: k_shade_all reads
+    // every level of a pixel at the end of the frame
+    const int occ_chunks = n_chunks > 0 ? n_chunks : 1;
+    auto hits_of = [&](int level) { return ws.p_hits + (size_t)level * (size_t)n_pixels; };
+    auto occ_of = [&](int level, int chunk) { return ws.p_occ + ((size_t)level * occ_chunks + chunk) * (size_t)n_pixels; };
 
     const int shade_grid = n_regions < num_cus * 8 ? n_regions : num_cus * 8;
     unsigned int *cursor = ws.trace_cursors;
@@ -628,7 +557,8 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         s.level = level; s.chunk = chunk;
         s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
         s.in_counts = ws.rq_counts[level & 1];
-        s.hits = ws.hits + (size_t)(level & 1) * ws.slots_cap;
+        s.hits = hits_of(level);
+        s.occ = occ_of(level, chunk);
         s.nq_o = ws.queue_o[(level + 1) & 1]; s.nq_d = ws.queue_d[(level + 1) & 1];
         s.out_counts = ws.rq_counts[(level + 1) & 1];
         if (level == 0) hipLaunchKernelGGL(k_shadow_gen<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
@@ -639,7 +569,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     auto launch_traversal = [&](int mode, int level, int chunk) -> int {
         t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
         const int close_level = mode == 2 ? level + 1 : level;
-        t.hits = ws.hits + (size_t)(close_level & 1) * ws.slots_cap;
+        t.hits = hits_of(close_level);
         if (mode == 0) {
             t.q_o = ws.queue_o[level & 1]; t.q_d = ws.queue_d[level & 1];
             t.counts = ws.rq_counts[level & 1];
@@ -648,7 +578,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         } else {
             t.q_o = ws.sq_o; t.q_d = ws.sq_d;
             t.counts = ws.sq_counts;
-            t.occ = ws.occ + (size_t)chunk * ws.slots_cap;
+            t.occ = occ_of(level, chunk);
             t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;
             t.seg_stride = (unsigned)ws.slots_cap;
             t.q2_o = ws.queue_o[(level + 1) & 1]; t.q2_d = ws.queue_d[(level + 1) & 1];
@@ -664,15 +594,6 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         else launch_trace<2, false>(t, count, grid, stream);
         launches++;
         return tstamp();
-    };
-    auto launch_shade = [&](int level) {
-        s.level = level;
-        s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
-        s.in_counts = ws.rq_counts[level & 1];
-        s.hits = ws.hits + (size_t)(level & 1) * ws.slots_cap;
-        if (level == 0) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
-        else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
-        launches++;
     };
     if (int rc = launch_traversal(0, 0, 0)) return rc;
     for (int level = 0; level <= fp.max_depth; level++) {
@@ -692,14 +613,18 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
             launch_gen(level, chunk);
             if (int rc = launch_traversal(1, level, chunk)) return rc;
         }
-        // ---- local colour and record (needs every chunk's occlusion bits)
-        launch_shade(level);
         if (int rc = stamp()) return rc;
         if (more && !next_traced)
             if (int rc = launch_traversal(0, level + 1, 0)) return rc;
     }
     RT_HIP_CHECK(hipGetLastError(), err);
     ws.trav_pairs = (int)(te / 2);
+    // ---- every level's local colour, the fold and the outputs, one thread per pixel
+    if (int rc = shade_all_launch(scene, cam, fp, ws.p_hits, ws.p_occ, occ_chunks, ws.records, ws.counters, d_rgb8, d_hit_id,
+                                  d_rgb32, d_hit_t, stream, num_cus, err))
+        return rc;
+    launches++;
+    if (int rc = stamp()) return rc;
     *n_launches += launches;
     return RT_OK;
 }
