@@ -7,6 +7,11 @@
 //   raytracer [--out frame.ppm] [--raw-order] [--pfm frame.pfm] [--ids ids.bin]
 //             [--width W] [--height H] [--depth D] [--obj mesh.obj] [--mesh-reflect K]
 //             [--no-mirror] [--no-floor] [--device N] [--dump-obj mesh.obj]
+//             [--relaxed] [--exr frame.exr] [--frames N] [--dump-obj-relaxed mesh.obj]
+//
+// --relaxed reads the OBJ with the tolerant parser and takes materials from its .mtl files;
+// --frames N re-renders from draw(dt) with the camera swinging sideways, N - 1 more times.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,8 +27,9 @@ namespace {
 
 struct Config {
     int imageWidth = 800, imageHeight = 600, maxDepth = 3;   // main.cpp:18
-    std::string out = "frame.ppm", pfm, ids, obj;
-    bool raw_order = false, mirror = true, floor = true;
+    std::string out = "frame.ppm", pfm, ids, obj, exr;
+    bool raw_order = false, mirror = true, floor = true, relaxed = false;
+    int frames = 1;
     float mesh_reflect = 0.0f;                               // main.cpp:34: meshes do not reflect
     int device = 0;
 } cfg;
@@ -33,6 +39,10 @@ std::vector<float> image_rgb32;
 std::vector<int32_t> image_ids;
 rt_ctx *ctx = nullptr;
 int exit_code = 0;
+int frames_rendered = 0;
+double total_rays = 0.0, total_device_ms = 0.0, clock_s = 0.0;
+rt_camera base_cam;
+bool render_once(bool report);
 
 rt_material material(float reflect, float diffuse, float spec, float r, float g, float b)
 {
@@ -68,6 +78,28 @@ bool check(int rc, const char *what)
 // triples to the GPU, which runs the Triangle constructor for each.
 bool LoadModel(const char *model)
 {
+    static_assert(sizeof(vec3) == 3 * sizeof(float), "vec3 must be packed");
+    if (cfg.relaxed) {
+        ObjModel m;
+        if (!LoadModelEx(model, m)) {
+            fprintf(stderr, "%s: cannot read\n", model);
+            exit_code = 1;
+            return false;
+        }
+        if (m.dropped_faces || m.missing_materials)
+            fprintf(stderr, "%s: %d face(s) dropped, %d unknown material name(s)\n", model, m.dropped_faces, m.missing_materials);
+        std::vector<rt_material> mats;
+        for (const ObjMaterial &om : m.materials)
+            mats.push_back(material(om.reflect, om.diffuse, om.spec, om.color[0], om.color[1], om.color[2]));
+        if (cfg.mesh_reflect > 0.0f) mats[0].reflect = cfg.mesh_reflect;      // faces without usemtl
+        if (!check(rt_set_mesh(ctx, m.vertices.empty() ? nullptr : &m.vertices[0].x, (int)m.vertices.size(), m.indices.data(),
+                               (int)m.indices.size(), &mats[0]),
+                   "rt_set_mesh"))
+            return false;
+        if (m.tri_material.empty()) return true;
+        return check(rt_set_triangle_materials(ctx, mats.data(), (int)mats.size(), m.tri_material.data(), (int)m.tri_material.size()),
+                     "rt_set_triangle_materials");
+    }
     std::vector<vec3> verts;
     std::vector<vec2> uvs;
     std::vector<vec3> normals;
@@ -79,12 +111,33 @@ bool LoadModel(const char *model)
         return false;
     }
     rt_material m = material(cfg.mesh_reflect, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f);
-    static_assert(sizeof(vec3) == 3 * sizeof(float), "vec3 must be packed");
     return check(rt_set_mesh(ctx, verts.empty() ? nullptr : &verts[0].x, (int)verts.size(), inds.data(), (int)inds.size(), &m),
                  "rt_set_mesh");
 }
 
+// One pass of the pixel loop (main.cpp:262-277) on the GPU into `image`.
+bool render_once(bool report)
+{
+    if (!check(rt_render_frame(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, (uint8_t *)image,
+                               image_ids.empty() ? nullptr : image_ids.data(),
+                               image_rgb32.empty() ? nullptr : image_rgb32.data()),
+               "rt_render_frame"))
+        return false;
+    rt_stats st;
+    if (!check(rt_get_stats(ctx, &st), "rt_get_stats")) return false;
+    const double rays = (double)(st.rays_primary + st.rays_shadow + st.rays_reflect);
+    frames_rendered++;
+    total_rays += rays;
+    total_device_ms += st.ms_frame;
+    if (report)
+        printf("Render took %f seconds (device), %.0f rays, %.1f Mrays/s\n", st.ms_frame * 1e-3, rays,   // main.cpp:279
+               st.ms_frame > 0 ? rays / (st.ms_frame * 1e3) : 0.0);
+    return true;
+}
+
 }  // namespace
+
+int glwt_headless_frames = 1;
 
 void setup()
 {
@@ -111,27 +164,19 @@ void setup()
     rt_camera cam = { { 0.0f, 0.0f, -5.0f }, 0.01f, -4.0f, -4.0f, 0.0f };
     if (cfg.imageWidth != 800) cam.pitch = 8.0f / (float)cfg.imageWidth;
     if (!check(rt_set_camera(ctx, &cam), "rt_set_camera")) return;
+    base_cam = cam;
 
     const size_t n = (size_t)cfg.imageWidth * cfg.imageHeight;
     image = new color[n];                                                       // main.cpp:259
-    if (!cfg.pfm.empty()) image_rgb32.resize(3 * n);
-    if (!cfg.ids.empty()) image_ids.resize(n);
+    if (!cfg.pfm.empty() || !cfg.exr.empty()) image_rgb32.resize(3 * n);
+    if (!cfg.ids.empty() || !cfg.exr.empty()) image_ids.resize(n);
 
     printf("Rendering...\n");                                                   // main.cpp:261
-    if (!check(rt_render_frame(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, (uint8_t *)image,
-                               image_ids.empty() ? nullptr : image_ids.data(),
-                               image_rgb32.empty() ? nullptr : image_rgb32.data()),
-               "rt_render_frame"))
-        return;
-    rt_stats st;
-    if (check(rt_get_stats(ctx, &st), "rt_get_stats")) {
-        double rays = (double)(st.rays_primary + st.rays_shadow + st.rays_reflect);
-        printf("Render took %f seconds (device), %.0f rays, %.1f Mrays/s\n", st.ms_frame * 1e-3, rays,   // main.cpp:279
-               st.ms_frame > 0 ? rays / (st.ms_frame * 1e3) : 0.0);
-    }
+    if (!render_once(true)) return;
 
     texturerenderer_set_output(cfg.out.empty() ? nullptr : cfg.out.c_str(), cfg.raw_order);
     if (!cfg.pfm.empty()) texturerenderer_set_float_output(cfg.pfm.c_str(), image_rgb32.data());
+    if (!cfg.exr.empty()) texturerenderer_set_exr_output(cfg.exr.c_str(), image_rgb32.data(), image_ids.data());
     texturerenderer_displaytexture(image, cfg.imageWidth, cfg.imageHeight);    // main.cpp:281
     if (!cfg.ids.empty()) {
         if (FILE *f = fopen(cfg.ids.c_str(), "wb")) {
@@ -141,8 +186,25 @@ void setup()
     }
 }
 
-void draw(float)
+// The reference's draw(dt) only re-presents the one frame of setup() (main.cpp:284-287).  With
+// --frames N every further tick re-renders: the scene and its hierarchy stay on the device, only
+// the camera moves (a sideways swing of the eye and of the image plane), which turns the one-shot
+// render into a sustained-throughput run.
+void draw(float dt)
 {
+    if (cfg.frames > 1 && ctx && image && exit_code == 0 && frames_rendered < cfg.frames) {
+        clock_s += dt;
+        rt_camera cam = base_cam;
+        const float swing = 1.5f * sinf((float)clock_s * 2.0f);
+        cam.origin[0] += swing;
+        cam.off_x += swing;
+        if (check(rt_set_camera(ctx, &cam), "rt_set_camera")) render_once(false);
+        if (frames_rendered == cfg.frames && total_device_ms > 0.0)
+            printf("%d frames, %.3f ms/frame (device), %.1f Mrays/s sustained\n", frames_rendered, total_device_ms / frames_rendered,
+                   total_rays / (total_device_ms * 1e3));
+        texturerenderer_displaytexture(image, cfg.imageWidth, cfg.imageHeight);
+        if (frames_rendered < cfg.frames) return;          // files are written once, with the last frame
+    }
     texturerenderer_draw();                                                     // main.cpp:284-287
 }
 
@@ -155,6 +217,20 @@ static int dump_obj(const char *path)
     printf("verts %zu texcoords %zu normals %zu indices %zu malformed %d\n", v.size(), t.size(), n.size(), idx.size(), malformed);
     for (const vec3 &p : v) printf("v %.9g %.9g %.9g\n", p.x, p.y, p.z);
     for (size_t i = 0; i < idx.size(); i++) printf("i %d\n", idx[i]);
+    return 0;
+}
+
+static int dump_obj_relaxed(const char *path)
+{
+    ObjModel m;
+    if (!LoadModelEx(path, m)) { printf("unreadable\n"); return 1; }
+    printf("verts %zu texcoords %zu normals %zu indices %zu materials %zu dropped %d missing %d\n", m.vertices.size(),
+           m.texcoords.size(), m.normals.size(), m.indices.size(), m.materials.size(), m.dropped_faces, m.missing_materials);
+    for (const vec3 &p : m.vertices) printf("v %.9g %.9g %.9g\n", p.x, p.y, p.z);
+    for (size_t i = 0; i < m.indices.size(); i++) printf("i %d\n", m.indices[i]);
+    for (size_t i = 0; i < m.tri_material.size(); i++) printf("t %d\n", m.tri_material[i]);
+    for (const ObjMaterial &om : m.materials)
+        printf("m %s|%.9g %.9g %.9g %.9g %.9g %.9g\n", om.name, om.reflect, om.diffuse, om.spec, om.color[0], om.color[1], om.color[2]);
     return 0;
 }
 
@@ -179,8 +255,13 @@ int main(int argc, char *argv[])
         else if (a == "--no-mirror") cfg.mirror = false;
         else if (a == "--no-floor") cfg.floor = false;
         else if (a == "--dump-obj") return dump_obj(val());
+        else if (a == "--dump-obj-relaxed") return dump_obj_relaxed(val());
+        else if (a == "--relaxed") cfg.relaxed = true;
+        else if (a == "--exr") cfg.exr = val();
+        else if (a == "--frames") cfg.frames = atoi(val());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
+    glwt_headless_frames = cfg.frames > 1 ? cfg.frames : 1;
     int rc = initglwt("Raytracer", cfg.imageWidth, cfg.imageHeight, false);    // main.cpp:291
     if (ctx) rt_destroy(ctx);
     delete[] image;

@@ -82,3 +82,173 @@ int LoadModel(const char *objFile, std::vector<vec3> &vertices, std::vector<vec2
     }
     return malformed;
 }
+
+// ------------------------------------------------------------------ tolerant parser with materials
+namespace {
+
+// Next whitespace-delimited token of [p, end); false at the end of the line.
+bool token(const char *&p, const char *end, std::string &tok)
+{
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+    if (p >= end || *p == '#') return false;
+    const char *q = p;
+    while (q < end && *q != ' ' && *q != '\t' && *q != '\r') q++;
+    tok.assign(p, q);
+    p = q;
+    return true;
+}
+
+bool read_floats(const char *&p, const char *end, float *dst, int n)
+{
+    std::string t;
+    for (int i = 0; i < n; i++) {
+        if (!token(p, end, t)) return false;
+        dst[i] = (float)atof(t.c_str());
+    }
+    return true;
+}
+
+ObjMaterial default_material(const char *name)
+{
+    ObjMaterial m;
+    memset(&m, 0, sizeof m);
+    snprintf(m.name, sizeof m.name, "%s", name);
+    m.reflect = 0.0f; m.diffuse = 1.0f; m.spec = 1.0f;         // Material(), main.cpp:34
+    m.color[0] = m.color[1] = m.color[2] = 1.0f;
+    return m;
+}
+
+bool read_file(const std::string &path, std::string &text)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    text.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    return true;
+}
+
+void load_mtl(const std::string &path, std::vector<ObjMaterial> &mats)
+{
+    std::string text;
+    if (!read_file(path, text)) return;
+    const char *p = text.data(), *fend = p + text.size();
+    int cur = -1;
+    bool has_ks = false, has_reflect = false;
+    int illum = -1;
+    float ks_max = 1.0f;
+    auto finish = [&]() {
+        if (cur < 0) return;
+        if (!has_reflect && illum >= 3 && illum <= 7) mats[(size_t)cur].reflect = has_ks ? ks_max : 1.0f;
+    };
+    std::string key, t;
+    while (p < fend) {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(fend - p));
+        if (!eol) eol = fend;
+        const char *q = p;
+        p = eol < fend ? eol + 1 : fend;
+        if (!token(q, eol, key)) continue;
+        if (key == "newmtl") {
+            finish();
+            if (!token(q, eol, t)) t = "";
+            mats.push_back(default_material(t.c_str()));
+            cur = (int)mats.size() - 1;
+            has_ks = has_reflect = false; illum = -1; ks_max = 1.0f;
+        } else if (cur >= 0 && key == "Kd") {
+            float c[3];
+            if (read_floats(q, eol, c, 3)) { mats[(size_t)cur].color[0] = c[0]; mats[(size_t)cur].color[1] = c[1]; mats[(size_t)cur].color[2] = c[2]; }
+        } else if (cur >= 0 && key == "Ks") {
+            float c[3];
+            if (read_floats(q, eol, c, 3)) {
+                ks_max = c[0] > c[1] ? (c[0] > c[2] ? c[0] : c[2]) : (c[1] > c[2] ? c[1] : c[2]);
+                mats[(size_t)cur].spec = ks_max;
+                has_ks = true;
+            }
+        } else if (cur >= 0 && key == "illum") {
+            float v;
+            if (read_floats(q, eol, &v, 1)) illum = (int)v;
+        } else if (cur >= 0 && key == "reflect") {
+            float v;
+            if (read_floats(q, eol, &v, 1)) { mats[(size_t)cur].reflect = v; has_reflect = true; }
+        }
+    }
+    finish();
+}
+
+}  // namespace
+
+bool LoadModelEx(const char *objFile, ObjModel &out)
+{
+    std::string text;
+    if (!read_file(objFile, text)) return false;
+    std::string dir(objFile);
+    size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+
+    out.materials.clear();
+    out.materials.push_back(default_material(""));
+    int cur_mat = 0;
+    const char *p = text.data(), *fend = p + text.size();
+    std::string key, t;
+    std::vector<int> corners;
+    while (p < fend) {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(fend - p));
+        if (!eol) eol = fend;
+        const char *q = p;
+        p = eol < fend ? eol + 1 : fend;
+        if (!token(q, eol, key)) continue;
+        if (key == "v") {
+            float c[3] = { 0.f, 0.f, 0.f };
+            read_floats(q, eol, c, 3);
+            out.vertices.push_back(vec3(c[0], c[1], c[2]));
+        } else if (key == "vt") {
+            float c[2] = { 0.f, 0.f };
+            read_floats(q, eol, c, 2);
+            out.texcoords.push_back(vec2(c[0], c[1]));
+        } else if (key == "vn") {
+            float c[3] = { 0.f, 0.f, 0.f };
+            read_floats(q, eol, c, 3);
+            out.normals.push_back(vec3(c[0], c[1], c[2]));
+        } else if (key == "mtllib") {
+            while (token(q, eol, t)) load_mtl(dir + t, out.materials);
+        } else if (key == "usemtl") {
+            cur_mat = 0;
+            if (token(q, eol, t)) {
+                bool found = false;
+                for (size_t i = 1; i < out.materials.size(); i++)
+                    if (t == out.materials[i].name) { cur_mat = (int)i; found = true; break; }
+                if (!found) out.missing_materials++;
+            }
+        } else if (key == "f") {
+            corners.clear();
+            bool ok = true;
+            while (token(q, eol, t)) {
+                char *endp = nullptr;
+                long v = strtol(t.c_str(), &endp, 10);          // position index = text before the first '/'
+                if (endp == t.c_str() || v == 0) { ok = false; break; }
+                long idx = v > 0 ? v - 1 : (long)out.vertices.size() + v;   // negative: relative to the vertices so far
+                if (idx < 0 || idx > 0x7ffffffe) { ok = false; break; }      // positive ones may point ahead: checked at the end
+                corners.push_back((int)idx);
+            }
+            if (!ok || corners.size() < 3) { out.dropped_faces++; continue; }
+            for (size_t k = 1; k + 1 < corners.size(); k++) {   // fan around corner 0, as objloader.cpp:90-99 does for quads
+                out.indices.push_back(corners[0]); out.indices.push_back(corners[k]); out.indices.push_back(corners[k + 1]);
+                out.tri_material.push_back(cur_mat);
+            }
+        }
+    }
+    // a positive index may name a vertex that comes later in the file; now every vertex is known
+    size_t kept = 0;
+    const int nv = (int)out.vertices.size();
+    for (size_t tri = 0; tri < out.tri_material.size(); tri++) {
+        const int a = out.indices[3 * tri], b = out.indices[3 * tri + 1], c = out.indices[3 * tri + 2];
+        if (a >= nv || b >= nv || c >= nv) { out.dropped_faces++; continue; }
+        out.indices[3 * kept] = a; out.indices[3 * kept + 1] = b; out.indices[3 * kept + 2] = c;
+        out.tri_material[kept++] = out.tri_material[tri];
+    }
+    out.indices.resize(3 * kept);
+    out.tri_material.resize(kept);
+    return true;
+}

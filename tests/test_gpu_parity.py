@@ -308,6 +308,95 @@ def test_host_application_loads_an_obj_and_writes_float_and_id_planes():
     assert_parity(compare(dict(rgb8=img, hit_id=hid, rgb32=f32), r))
 
 
+def _read_exr(path):
+    """Reader for the uncompressed scanline EXR files the host writes: {channel: (H, W) array}, top row first."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and b[4] == 2
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        n = struct.unpack_from("<i", b, pos)[0]; pos += 4
+        attrs[name] = (typ, b[pos:pos + n]); pos += n
+    pos += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    W, H = x1 - x0 + 1, y1 - y0 + 1
+    chans, cp, cl = [], 0, attrs["channels"][1]
+    while cl[cp] != 0:
+        e = cl.index(b"\0", cp); nm = cl[cp:e].decode(); cp = e + 1
+        ptype = struct.unpack_from("<i", cl, cp)[0]; cp += 16
+        chans.append((nm, ptype))
+    assert [c for c, _ in chans] == sorted(c for c, _ in chans)
+    offs = struct.unpack_from("<%dQ" % H, b, pos)
+    out = {nm: np.zeros((H, W), np.float32 if pt == 2 else np.uint32) for nm, pt in chans}
+    for y in range(H):
+        yy, size = struct.unpack_from("<2i", b, offs[y])
+        assert yy == y and size == 4 * W * len(chans)
+        q = offs[y] + 8
+        for nm, pt in chans:
+            out[nm][y] = np.frombuffer(b, np.float32 if pt == 2 else np.uint32, W, q)
+            q += 4 * W
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_relaxed_obj_with_mtl_materials_and_exr_output():
+    """Materials come from the .mtl (per-triangle table), the frame goes out as EXR: checked against the
+    oracle given the same per-triangle materials."""
+    from common import SceneSpec, stock_analytic
+    v, q = scenes.cube_quads()
+    v = np.asarray(v, np.float32)
+    mats = [(0.0, 1.0, 1.0, (1.0, 1.0, 1.0)), (0.0, 1.0, 0.5, (0.8, 0.1, 0.1)), (0.9, 1.0, 0.9, (1.0, 1.0, 1.0))]
+    with tempfile.TemporaryDirectory() as td:
+        obj, exr, ppm = (os.path.join(td, n) for n in ("c.obj", "f.exr", "f.ppm"))
+        with open(os.path.join(td, "c.mtl"), "w") as f:
+            f.write("newmtl red\nKd 0.8 0.1 0.1\nKs 0.5 0.25 0.1\nillum 2\nnewmtl mirror\nKs 0.9 0.9 0.9\nillum 3\n")
+        with open(obj, "w") as f:
+            f.write("mtllib c.mtl\r\n")
+            for p in v:
+                f.write("v   %r %r\t%r\r\n" % (float(p[0]), float(p[1]), float(p[2])))
+            for k, quad in enumerate(q):
+                if k == 2: f.write("usemtl red\r\n")
+                if k == 4: f.write("usemtl mirror\r\n")
+                f.write("f  " + "  ".join(str(int(c) + 1) for c in quad) + "\r\n")
+        subprocess.run([HOST_BIN, "--obj", obj, "--relaxed", "--no-mirror", "--width", "400", "--height", "300", "--depth", "3",
+                        "--out", ppm, "--raw-order", "--exr", exr], check=True, capture_output=True, timeout=120)
+        img, _ = _read_ppm(ppm)
+        ex = _read_exr(exr)
+    idx = np.array([[a, b, c, a, c, d] for a, b, c, d in q], np.int32).reshape(-1)
+    tri_mat = np.repeat([0, 0, 1, 1, 2, 2], 2).astype(np.int32)
+    spec = SceneSpec(stock_analytic(mirror=False), v, idx, mats=mats, tri_material=tri_mat)
+    r = to_oracle(spec).render(400, 300, max_depth=3, cam=ocam(rt.camera_for_width(400)), threads=8)
+    f32 = np.stack([ex["R"], ex["G"], ex["B"]], -1)[::-1]             # EXR is top row first
+    hid = ex["id"][::-1].astype(np.int64) - 1
+    assert_parity(compare(dict(rgb8=img, hit_id=hid.astype(np.int32), rgb32=np.ascontiguousarray(f32)), r))
+    assert (hid >= 4).sum() > 1000                                       # the cube is in view
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_multi_frame_draw_loop_rerenders_with_a_moving_camera():
+    """--frames N: draw(dt) re-renders N - 1 times; the last frame equals the oracle at the camera of that tick."""
+    spec = stock_spec()
+    N = 4
+    with tempfile.TemporaryDirectory() as td:
+        ppm = os.path.join(td, "f.ppm")
+        out = subprocess.run([HOST_BIN, "--frames", str(N), "--width", "320", "--height", "240", "--out", ppm, "--raw-order"],
+                             check=True, capture_output=True, text=True, timeout=120).stdout
+        img, _ = _read_ppm(ppm)
+    assert "%d frames" % N in out and "sustained" in out
+    # draw(dt) advances a double clock by float(1/60) per tick; the swing is 1.5f * sinf((float)clock * 2.0f)
+    clock = float(np.float32(1.0) / np.float32(60.0)) * (N - 1)
+    swing = np.float32(1.5) * np.float32(np.sin(np.float32(np.float32(clock) * np.float32(2.0)), dtype=np.float32))
+    base = rt.camera_for_width(320)
+    cam = rt.Camera(origin=(float(np.float32(base.origin[0]) + swing), base.origin[1], base.origin[2]), pitch=base.pitch,
+                    off_x=float(np.float32(base.off_x) + swing), off_y=base.off_y, plane_z=base.plane_z)
+    r = to_oracle(spec).render(320, 240, max_depth=3, cam=ocam(cam), threads=8)
+    d = np.abs(img.astype(int) - r["rgb8"].astype(int)).max(-1)
+    assert (d > 1).mean() < 0.001
+
+
 # ------------------------------------------------------------------ many lights / no lights through the LBVH stages
 def _ring_of_lights(n):
     from common import sphere

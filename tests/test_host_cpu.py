@@ -121,3 +121,74 @@ def test_scenes_are_deterministic_and_sized():
 
 def test_camera_pitch_at_800_is_the_reference_literal():
     assert np.float32(rt.camera_for_width(800).pitch).view(np.uint32) == np.float32(0.01).view(np.uint32)
+
+
+# ------------------------------------------------------------------ tolerant OBJ + MTL loader (beyond the reference)
+def _dump_relaxed(path):
+    out = subprocess.run([HOST_BIN, "--dump-obj-relaxed", path], check=True, capture_output=True, text=True).stdout.splitlines()
+    head = dict(zip(out[0].split()[0::2], map(int, out[0].split()[1::2])))
+    v = np.array([[float(x) for x in l.split()[1:]] for l in out if l.startswith("v ")], np.float32).reshape(-1, 3)
+    i = [int(l.split()[1]) for l in out if l.startswith("i ")]
+    t = [int(l.split()[1]) for l in out if l.startswith("t ")]
+    m = []
+    for l in out:
+        if l.startswith("m "):
+            name, vals = l[2:].split("|")
+            m.append((name, [float(x) for x in vals.split()]))
+    return head, v, i, t, m
+
+
+RELAXED_OBJ = (
+    "# a comment\r\n"
+    "mtllib  a.mtl   b.mtl\r\n"
+    "v  0 0 0\r\n"
+    "v\t1   0 0\r\n"
+    "v 1 1 0\r\n"
+    "v 0 1 0  # trailing comment\r\n"
+    "v 0.5 1.5 0\r\n"
+    "vn 0 0 1\r\n"
+    "vt 0.5 0.5\r\n"
+    "usemtl red\r\n"
+    "f 1/1/1  2/1/1   3/1/1\r\n"            # runs of spaces, full corner syntax
+    "usemtl mirror\r\n"
+    "f -5 -4 -3 -2 -1\r\n"                  # relative indices, five corners -> 3 triangles
+    "usemtl nosuch\r\n"
+    "f 1//1 3//1 6//1\r\n"                  # forward reference to vertex 6, defined below
+    "f 1 2 99\r\n"                          # out of range -> dropped
+    "f 1 2\r\n"                             # two corners -> dropped
+    "v 2 2 2\r\n"
+)
+A_MTL = "newmtl red\nKd 0.8 0.1 0.1\nKs 0.5 0.25 0.1\nillum 2\n"
+B_MTL = "# second library\r\nnewmtl mirror\r\nKd 1 1 1\r\nKs 0.9 0.9 0.9\r\nillum 3\r\nnewmtl glass\r\nillum 5\r\nreflect 0.25\r\n"
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_relaxed_loader_handles_what_the_reference_parser_cannot():
+    with tempfile.TemporaryDirectory() as td:
+        for name, text in (("m.obj", RELAXED_OBJ), ("a.mtl", A_MTL), ("b.mtl", B_MTL)):
+            with open(os.path.join(td, name), "wb") as f:
+                f.write(text.encode())
+        head, v, i, t, m = _dump_relaxed(os.path.join(td, "m.obj"))
+    assert head["verts"] == 6 and head["normals"] == 1 and head["texcoords"] == 1
+    assert np.array_equal(v[1], [1, 0, 0]) and np.array_equal(v[5], [2, 2, 2])
+    assert i == [0, 1, 2,  0, 1, 2, 0, 2, 3, 0, 3, 4,  0, 2, 5]
+    assert head["dropped"] == 2 and head["missing"] == 1
+    names = [n for n, _ in m]
+    assert names == ["", "red", "mirror", "glass"]
+    assert t == [1, 2, 2, 2, 0]                                    # unknown material falls back to the default
+    assert m[0][1] == [0.0, 1.0, 1.0, 1.0, 1.0, 1.0]               # Material(), main.cpp:34
+    assert np.allclose(m[1][1], [0.0, 1.0, 0.5, 0.8, 0.1, 0.1])    # illum 2: no reflection, spec = max Ks
+    assert np.allclose(m[2][1], [0.9, 1.0, 0.9, 1.0, 1.0, 1.0])    # illum 3: reflect = max Ks
+    assert np.allclose(m[3][1], [0.25, 1.0, 1.0, 1.0, 1.0, 1.0])   # explicit `reflect` wins
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_relaxed_loader_equals_the_strict_one_on_a_clean_file():
+    v, q = scenes.cube_quads()
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "cube.obj")
+        scenes.write_obj(p, v, q)
+        head, sv, si = _dump(p)
+        rhead, rv, ri, rt_, rm = _dump_relaxed(p)
+    assert np.array_equal(rv.reshape(-1), sv) and ri == si
+    assert rt_ == [0] * (len(si) // 3) and rhead["dropped"] == 0 and len(rm) == 1
