@@ -432,13 +432,40 @@ __global__ void k_refit_level(const int2 *__restrict__ children, const int *__re
     box_hi[i] = make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), 0.f);
 }
 
+// Depth-first (preorder) numbering of the nodes that traversal can reach, so that a node's first
+// child is the next node in memory (4 lattice nodes share a 128-byte line) and every subtree is
+// contiguous.  live[i] = reachable inner nodes in the subtree of i, bottom-up one level per launch;
+// pre[i] = position, top-down.
+__global__ void k_live_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int2 *__restrict__ range,
+                             int n, int leaf_max, int level, int *live)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || depth[i] != level) return;
+    const int2 r = range[i];
+    if (i != 0 && r.y - r.x + 1 <= leaf_max) { live[i] = 0; return; }
+    const int2 c = children[i];
+    live[i] = 1 + (c.x < n - 1 ? live[c.x] : 0) + (c.y < n - 1 ? live[c.y] : 0);
+}
+
+__global__ void k_pre_level(const int2 *__restrict__ children, const int *__restrict__ depth, int n, int level,
+                            const int *__restrict__ live, int *pre)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || depth[i] != level || live[i] == 0) return;
+    const int2 c = children[i];
+    const int p = pre[i];
+    const int lx = c.x < n - 1 ? live[c.x] : 0;
+    if (lx) pre[c.x] = p + 1;
+    if (c.y < n - 1 && live[c.y]) pre[c.y] = p + 1 + lx;
+}
+
 // Traversal nodes.  A child whose sorted range holds <= leaf_max triangles becomes
 // a leaf reference ~(first*8 + count-1); nodes inside such a subtree are never
 // reached and are left zeroed.
 __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
-                       const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, BvhNode *nodes, BvhNodeQ *qnodes,
-                       QuantGrid *grid, int *live_depth)
+                       const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre,
+                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -468,7 +495,7 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
         } else {
             int2 r = range[cc[k]];
             int cnt = r.y - r.x + 1;
-            enc[k] = (cnt <= leaf_max) ? ~((r.x << 3) | (cnt - 1)) : cc[k];
+            enc[k] = (cnt <= leaf_max) ? ~((r.x << 3) | (cnt - 1)) : pre[cc[k]];
         }
     }
     float4 l0 = box_lo[c.x], h0 = box_hi[c.x], l1 = box_lo[c.y], h1 = box_hi[c.y];
@@ -477,7 +504,7 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     nd.xy1 = make_float4(l1.x, h1.x, l1.y, h1.y);
     nd.z01 = make_float4(l0.z, h0.z, l1.z, h1.z);
     nd.ch = make_int4(enc[0], enc[1], 0, 0);
-    nodes[i] = nd;
+    nodes[pre[i]] = nd;
     // The same two boxes rounded OUTWARD onto the lattice: base + q*step <= lo and >= hi (computed in
     // double so the floor/ceil are exact), 32 bytes per node instead of 64.
     const float lo[2][3] = { { l0.x, l0.y, l0.z }, { l1.x, l1.y, l1.z } }, hi[2][3] = { { h0.x, h0.y, h0.z }, { h1.x, h1.y, h1.z } };
@@ -496,8 +523,94 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     BvhNodeQ qn;
     qn.a = make_uint4(w[0], w[1], w[2], w[3]);
     qn.b = make_uint4(w[4], w[5], (unsigned int)enc[0], (unsigned int)enc[1]);
-    qnodes[i] = qn;
+    qnodes[pre[i]] = qn;
     atomicMax(live_depth, depth[i] + 1);
+}
+
+// ---- 4-wide nodes.  A binary node at an even depth whose subtree is not collapsed becomes a wide node;
+// its children are its grandchildren (a child that is a leaf stays one child), so a ray that would
+// take two dependent node fetches takes one.  wide[i] = wide nodes in the subtree of binary node i
+// (bottom-up), pre4[i] = preorder position among the wide nodes (top-down).
+__global__ void k_wide_live_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int *__restrict__ live,
+                                  int n, int level, int *wide)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || depth[i] != level) return;
+    if (live[i] == 0) { wide[i] = 0; return; }
+    const int2 c = children[i];
+    wide[i] = ((level & 1) == 0 ? 1 : 0) + (c.x < n - 1 ? wide[c.x] : 0) + (c.y < n - 1 ? wide[c.y] : 0);
+}
+
+__global__ void k_wide_pre_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int *__restrict__ live,
+                                 const int *__restrict__ wide, int n, int level, int *pre4)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || depth[i] != level || live[i] == 0) return;
+    const int2 c = children[i];
+    const int first = pre4[i] + ((level & 1) == 0 ? 1 : 0);
+    if (c.x < n - 1 && live[c.x]) pre4[c.x] = first;
+    if (c.y < n - 1 && live[c.y]) pre4[c.y] = first + (c.x < n - 1 ? wide[c.x] : 0);
+}
+
+// A box rounded OUTWARD onto the 15-bit lattice, one word per axis: (0x8000 | lo) | (0x8000 | hi) << 16.
+__device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, const float *gs, unsigned int *w)
+{
+    const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+    for (int k = 0; k < 3; k++) {
+        double ql = floor(((double)l[k] - (double)gb[k]) / (double)gs[k]);
+        double qh = ceil(((double)h[k] - (double)gb[k]) / (double)gs[k]);
+        ql = fmin(fmax(ql, 0.0), 32767.0);
+        qh = fmin(fmax(qh, 0.0), 32767.0);
+        w[k] = (0x8000u | (unsigned int)ql) | ((0x8000u | (unsigned int)qh) << 16);
+    }
+}
+
+__global__ void k_emit_wide(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
+                            const int *__restrict__ live, int n, int leaf_max, const float4 *__restrict__ box_lo,
+                            const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
+                            BvhNode4 *wnodes, int *wide_depth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || live[i] == 0 || (depth[i] & 1)) return;
+    const float4 rlo = box_lo[0], rhi = box_hi[0];
+    const float gb[3] = { rlo.x, rlo.y, rlo.z };
+    float gs[3] = { (rhi.x - rlo.x) * (1.0f / 32767.0f), (rhi.y - rlo.y) * (1.0f / 32767.0f), (rhi.z - rlo.z) * (1.0f / 32767.0f) };
+    for (int k = 0; k < 3; k++)
+        if (!(gs[k] > 0.0f)) gs[k] = 1e-30f;
+    // slot list: (binary node or leaf id, reference)
+    int who[4], ref[4], m = 0;
+    auto leaf_ref = [&](int c, int &r) -> bool {        // true when c is referenced as a leaf
+        if (c >= n - 1) { const int j = c - (n - 1); r = ~(((leafpos ? leafpos[j] : j) << 3) | 0); return true; }
+        const int2 rg = range[c];
+        const int cnt = rg.y - rg.x + 1;
+        if (cnt <= leaf_max) { r = ~((rg.x << 3) | (cnt - 1)); return true; }
+        return false;
+    };
+    const int2 c = children[i];
+    const int cc[2] = { c.x, c.y };
+    for (int k = 0; k < 2; k++) {
+        int r;
+        if (leaf_ref(cc[k], r)) { who[m] = cc[k]; ref[m++] = r; continue; }
+        const int2 g = children[cc[k]];                 // an inner child at an odd depth: take its children
+        const int gg[2] = { g.x, g.y };
+        for (int q = 0; q < 2; q++) {
+            int r2;
+            who[m] = gg[q];
+            ref[m++] = leaf_ref(gg[q], r2) ? r2 : pre4[gg[q]];
+        }
+    }
+    unsigned int w[12];
+    for (int k = 0; k < 4; k++) {
+        if (k < m) lattice_box(box_lo[who[k]], box_hi[who[k]], gb, gs, w + 3 * k);
+        else { w[3 * k] = w[3 * k + 1] = w[3 * k + 2] = 0x8000ffffu; ref[k] = 0x7fffffff; }   // lo = 32767 > hi = 0: never entered
+    }
+    BvhNode4 nd;
+    nd.a = make_uint4(w[0], w[1], w[2], w[3]);
+    nd.b = make_uint4(w[4], w[5], w[6], w[7]);
+    nd.c = make_uint4(w[8], w[9], w[10], w[11]);
+    nd.d = make_uint4((unsigned)ref[0], (unsigned)ref[1], (unsigned)ref[2], (unsigned)ref[3]);
+    wnodes[pre4[i]] = nd;
+    atomicMax(wide_depth, depth[i] / 2 + 1);
 }
 
 __global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals,
@@ -550,6 +663,7 @@ void lbvh_free(LbvhResult *r)
 {
     if (r->nodes) (void)hipFree(r->nodes);
     if (r->qnodes) (void)hipFree(r->qnodes);
+    if (r->wnodes) (void)hipFree(r->wnodes);
     if (r->bvh_tri) (void)hipFree(r->bvh_tri);
     *r = LbvhResult();
 }
@@ -579,11 +693,12 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(bounds.alloc(6)); A(vals[0].alloc(n)); A(vals[1].alloc(n)); A(keys[0].alloc(n)); A(keys[1].alloc(n));
     A(hist.alloc((size_t)256 * n_tiles)); A(children.alloc(n)); A(range.alloc(n)); A(parent.alloc(2 * (size_t)n));
-    A(depth.alloc(n)); A(scalars.alloc(2)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
+    A(depth.alloc(n)); A(scalars.alloc(4)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
     DevBuf<QuantGrid> grid;
     A(grid.alloc(1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->qnodes, sizeof(BvhNodeQ) * (size_t)(n - 1)));
+    A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
     if (e != hipSuccess) {
         if (err) *err = std::string("lbvh_build allocation: ") + hipGetErrorString(e);
@@ -608,9 +723,10 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
                            n_tiles, keys[cur ^ 1].p, vals[cur ^ 1].p);
         cur ^= 1;
     }
-    RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 2 * sizeof(int), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->qnodes, 0, sizeof(BvhNodeQ) * (size_t)(n - 1), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * (size_t)(n - 1), stream), err);
     const bool ploc = builder != 1;
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
@@ -667,15 +783,43 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
                                offset.p);
         hipLaunchKernelGGL(k_dfs_finish, dim3(G), dim3(B), 0, stream, offset.p, size.p, n, range.p, leafpos.p, order.p);
     }
+    DevBuf<int> live, pre;
+    if (live.alloc(n) != hipSuccess || pre.alloc(n) != hipSuccess) {
+        if (err) *err = "node order allocation failed";
+        lbvh_free(out);
+        return RT_E_NOMEM;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(pre.p, 0, sizeof(int) * (size_t)n, stream), err);
+    for (int level = max_depth; level >= 0; level--)
+        hipLaunchKernelGGL(k_live_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, range.p, n, leaf_max,
+                           level, live.p);
+    for (int level = 0; level <= max_depth; level++)
+        hipLaunchKernelGGL(k_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n, level, live.p, pre.p);
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
-                       leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, out->nodes, out->qnodes, grid.p,
-                       scalars.p + 1);
+                       leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes, out->qnodes,
+                       grid.p, scalars.p + 1);
+    DevBuf<int> wide, pre4;
+    if (wide.alloc(n) != hipSuccess || pre4.alloc(n) != hipSuccess) {
+        if (err) *err = "wide node allocation failed";
+        lbvh_free(out);
+        return RT_E_NOMEM;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(pre4.p, 0, sizeof(int) * (size_t)n, stream), err);
+    for (int level = max_depth; level >= 0; level--)
+        hipLaunchKernelGGL(k_wide_live_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, n, level,
+                           wide.p);
+    for (int level = 0; level <= max_depth; level++)
+        hipLaunchKernelGGL(k_wide_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, wide.p, n,
+                           level, pre4.p);
+    hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p, n, leaf_max,
+                       box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, out->wnodes, scalars.p + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
     RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
-    int live_depth = 0;
+    int live_depth = 0, wide_depth = 0;
     RT_HIP_CHECK(hipMemcpyAsync(&live_depth, scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+    RT_HIP_CHECK(hipMemcpyAsync(&wide_depth, scalars.p + 2, sizeof(int), hipMemcpyDeviceToHost, stream), err);
     RT_HIP_CHECK(hipMemcpyAsync(&out->grid, grid.p, sizeof(QuantGrid), hipMemcpyDeviceToHost, stream), err);
     RT_HIP_CHECK(hipStreamSynchronize(stream), err);
     float ms = 0.f;
@@ -684,6 +828,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     (void)hipEventDestroy(ev1);
     out->n_nodes = n - 1;
     out->depth = live_depth;
+    out->wide_depth = wide_depth;
     out->leaf_max = leaf_max;
     out->ms_build = ms;
     return RT_OK;

@@ -49,6 +49,15 @@ struct BvhNodeQ {
     uint4 b;      // child1 y, child1 z, child0 ref, child1 ref
 };
 
+// Four children per node on the same lattice, 64 B: one dependent fetch where the binary tree needs two.
+// An unused slot holds an inverted box (never entered).
+struct BvhNode4 {
+    uint4 a;      // child0 x, y, z, child1 x          (each word lo | hi << 16)
+    uint4 b;      // child1 y, z, child2 x, y
+    uint4 c;      // child2 z, child3 x, y, z
+    uint4 d;      // child references 0..3 (inner: wide node index; negative: leaf, as in BvhNode)
+};
+
 struct QuantGrid {
     float base[3], step[3];
 };
@@ -62,6 +71,7 @@ struct DevScene {
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
     const BvhNodeQ *qnodes;        // same tree, quantised boxes
+    const BvhNode4 *wnodes;        // the tree collapsed to four children per node
     QuantGrid grid;
     const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
     int32_t n_analytic, n_lights, n_tris, accel;
@@ -89,9 +99,10 @@ struct FrameCounters {
 struct LbvhResult {
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
     BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
+    BvhNode4 *wnodes = nullptr;    // [max(n_tris-1,1)] (about a quarter used)
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
-    int n_nodes = 0, depth = 0, leaf_max = 0, builder = 0;
+    int n_nodes = 0, depth = 0, wide_depth = 0, leaf_max = 0, builder = 0;
     float ms_build = 0.f;
 };
 
@@ -113,6 +124,7 @@ struct FrameParams {
     int count_tests;
     int timing;
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
+    int wide_depth;                // depth of the 4-wide tree
     int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages, 3 single traversal launch
 };
 

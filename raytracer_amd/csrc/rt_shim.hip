@@ -294,13 +294,14 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
     sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.mats = c->d_mats;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
 
     FrameParams fp;
     fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
     fp.count_tests = c->opt_count; fp.timing = c->opt_timing;
     fp.stack_depth = accel ? c->bvh.depth : 0;
+    fp.wide_depth = accel ? c->bvh.wide_depth : 0;
     fp.pipeline = c->opt_pipeline;
     if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
     std::string err;

@@ -55,6 +55,9 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_LEAF_MIN
 #define WF_LEAF_MIN 0
 #endif
+#ifndef WF_WIDE
+#define WF_WIDE 1          // traverse the 4-wide nodes (one dependent fetch per two binary levels)
+#endif
 #ifndef WF_MERGE
 #define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
 #endif
@@ -245,22 +248,56 @@ void k_trace(TraceArgs A)
         if (do_node) {
             // ---- inner-node step: both children's lattice boxes from one 32-byte node
             if ((unsigned)node < SENT_U) {
+                const float tmax = ANYHIT ? FLT_MAX : best_t;      // mixed: a shadow lane's best_t stays FLT_MAX
+#if WF_WIDE
+                // four children from one 64-byte node; the lattice boxes contain the padded float boxes
+                const BvhNode4 *np = sc.wnodes + node;
+                const uint4 qa = np->a, qb = np->b, qc = np->c, qd = np->d;
+                float dk[4];
+                int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
+                {
+                    const unsigned int wx[4] = { qa.x, qa.w, qb.z, qc.y }, wy[4] = { qa.y, qb.x, qb.w, qc.z },
+                                       wz[4] = { qa.z, qb.y, qc.x, qc.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const V2 x = plane_pair(wx[k], sel_n.x, sel_f.x, inv.x, oi.x), y = plane_pair(wy[k], sel_n.y, sel_f.y, inv.y, oi.y),
+                                 z = plane_pair(wz[k], sel_n.z, sel_f.z, inv.z, oi.z);
+                        const float nk = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), 0.0f);
+                        const float fk = fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), tmax);
+                        dk[k] = nk <= fk ? nk : FLT_MAX;           // entry distance, or "missed" (unused slots always miss)
+                    }
+                }
+                if (COUNT) tl.box += 4;
+                const int n_hit = (dk[0] < FLT_MAX) + (dk[1] < FLT_MAX) + (dk[2] < FLT_MAX) + (dk[3] < FLT_MAX);
+                // nearest first: a five-exchange sorting network on (distance, reference)
+#define WF_CSWAP(a, b)                                                          \
+                {                                                               \
+                    const bool sw = dk[b] < dk[a];                              \
+                    const float td = sw ? dk[b] : dk[a];                        \
+                    const int tr = sw ? rk[b] : rk[a];                          \
+                    dk[b] = sw ? dk[a] : dk[b];                                 \
+                    rk[b] = sw ? rk[a] : rk[b];                                 \
+                    dk[a] = td;                                                 \
+                    rk[a] = tr;                                                 \
+                }
+                WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2) WF_CSWAP(1, 3) WF_CSWAP(1, 2)
+#undef WF_CSWAP
+                if (n_hit == 0) {
+                    pop();
+                } else {
+                    if (n_hit > 3) push(rk[3]);
+                    if (n_hit > 2) push(rk[2]);
+                    if (n_hit > 1) push(rk[1]);
+                    node = rk[0];
+                }
+#else
+                // ---- both children's lattice boxes from one 32-byte node
                 const BvhNodeQ *np = sc.qnodes + node;
                 const uint4 qa = np->a, qb = np->b;
                 const int2 ch = make_int2((int)qb.z, (int)qb.w);
-                const float tmax = ANYHIT ? FLT_MAX : best_t;      // mixed: a shadow lane's best_t stays FLT_MAX
-                // one fma per box plane; the lattice boxes contain the padded float boxes.  The ray's
-                // direction signs decide which plane of each pair is entered first, so no min/max per axis;
-                // one v_perm_b32 per plane builds its float, and the two planes of a pair share a packed fma.
-                const V2 x0 = plane_pair(qa.x, sel_n.x, sel_f.x, inv.x, oi.x), y0 = plane_pair(qa.y, sel_n.y, sel_f.y, inv.y, oi.y),
-                         z0 = plane_pair(qa.z, sel_n.z, sel_f.z, inv.z, oi.z);
-                const V2 x1 = plane_pair(qa.w, sel_n.x, sel_f.x, inv.x, oi.x), y1 = plane_pair(qb.x, sel_n.y, sel_f.y, inv.y, oi.y),
-                         z1 = plane_pair(qb.y, sel_n.z, sel_f.z, inv.z, oi.z);
-                const float n0 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x0.x, y0.x), z0.x), 0.0f);
-                const float f0 = fminf(__builtin_fminf(__builtin_fminf(x0.y, y0.y), z0.y), tmax);
-                const float n1 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x1.x, y1.x), z1.x), 0.0f);
-                const float f1 = fminf(__builtin_fminf(__builtin_fminf(x1.y, y1.y), z1.y), tmax);
-                const bool h0 = n0 <= f0, h1 = n1 <= f1;
+                float n0, n1;
+                bool h0, h1;
+                node_test(qa, qb, inv, oi, sel_n, sel_f, tmax, n0, n1, h0, h1);
                 if (COUNT) tl.box += 2;
                 if (h0 && h1) {
                     const bool swap = (WF_ANYHIT_NEAR || !ANYHIT) && n1 < n0;
@@ -273,6 +310,7 @@ void k_trace(TraceArgs A)
                 } else {
                     pop();
                 }
+#endif
             }
         }
         if (do_leaf) {
@@ -505,7 +543,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     const int n_chunks = (scene.n_lights + 31) / 32;
     const int trace_grid = wavefront_trace_grid(num_cus);
     const bool count = fp.count_tests != 0;
-    if (fp.stack_depth + 1 > WF_LDS_STACK + WF_OVF) {
+    if ((WF_WIDE ? 3 * fp.wide_depth + 1 : fp.stack_depth + 1) > WF_LDS_STACK + WF_OVF) {
         if (err) *err = "LBVH deeper than the traversal stack";
         return RT_E_LIMIT;
     }
