@@ -552,6 +552,43 @@ __global__ void k_wide_pre_level(const int2 *__restrict__ children, const int *_
     if (c.y < n - 1 && live[c.y]) pre4[c.y] = first + (c.x < n - 1 ? wide[c.x] : 0);
 }
 
+// The top of the wide tree (wide depths 0..WIDE_TOP_LEVELS-1) is numbered as a complete 4-ary tree
+// (root 0, children of slot s at 4s+1..4s+4) so that it sits at the start of the node array, where the
+// traversal kernel keeps a copy in LDS; every other wide node follows in preorder.
+__device__ __forceinline__ int wide_index(int i, const int *depth, const int *slot, const int *pre4)
+{
+    return depth[i] / 2 < WIDE_TOP_LEVELS ? slot[i] : WIDE_TOP_NODES + pre4[i];
+}
+
+// Children of wide node i in slot order: binary node ids (>= n-1: a single triangle), at most 4.
+__device__ __forceinline__ int wide_children(int i, const int2 *children, const int2 *range, int n, int leaf_max, int *who)
+{
+    int m = 0;
+    const int2 c = children[i];
+    const int cc[2] = { c.x, c.y };
+    for (int k = 0; k < 2; k++) {
+        bool leaf = cc[k] >= n - 1;
+        if (!leaf) { const int2 rg = range[cc[k]]; leaf = rg.y - rg.x + 1 <= leaf_max; }
+        if (leaf) { who[m++] = cc[k]; continue; }
+        const int2 g = children[cc[k]];                 // an inner child at an odd depth: take its children
+        who[m++] = g.x;
+        who[m++] = g.y;
+    }
+    return m;
+}
+
+__global__ void k_wide_slots(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
+                             const int *__restrict__ live, int n, int leaf_max, int wide_level, int *slot)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || live[i] == 0 || depth[i] != 2 * wide_level) return;
+    int who[4];
+    const int m = wide_children(i, children, range, n, leaf_max, who);
+    const int s = slot[i];
+    for (int k = 0; k < m; k++)
+        if (who[k] < n - 1 && live[who[k]]) slot[who[k]] = 4 * s + 1 + k;
+}
+
 // A box rounded OUTWARD onto the 15-bit lattice, one word per axis: (0x8000 | lo) | (0x8000 | hi) << 16.
 __device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, const float *gs, unsigned int *w)
 {
@@ -568,7 +605,7 @@ __device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, c
 __global__ void k_emit_wide(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
                             const int *__restrict__ live, int n, int leaf_max, const float4 *__restrict__ box_lo,
                             const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
-                            BvhNode4 *wnodes, int *wide_depth)
+                            const int *__restrict__ slot, BvhNode4 *wnodes, int *wide_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1 || live[i] == 0 || (depth[i] & 1)) return;
@@ -577,26 +614,18 @@ __global__ void k_emit_wide(const int2 *__restrict__ children, const int2 *__res
     float gs[3] = { (rhi.x - rlo.x) * (1.0f / 32767.0f), (rhi.y - rlo.y) * (1.0f / 32767.0f), (rhi.z - rlo.z) * (1.0f / 32767.0f) };
     for (int k = 0; k < 3; k++)
         if (!(gs[k] > 0.0f)) gs[k] = 1e-30f;
-    // slot list: (binary node or leaf id, reference)
-    int who[4], ref[4], m = 0;
-    auto leaf_ref = [&](int c, int &r) -> bool {        // true when c is referenced as a leaf
-        if (c >= n - 1) { const int j = c - (n - 1); r = ~(((leafpos ? leafpos[j] : j) << 3) | 0); return true; }
-        const int2 rg = range[c];
-        const int cnt = rg.y - rg.x + 1;
-        if (cnt <= leaf_max) { r = ~((rg.x << 3) | (cnt - 1)); return true; }
-        return false;
-    };
-    const int2 c = children[i];
-    const int cc[2] = { c.x, c.y };
-    for (int k = 0; k < 2; k++) {
-        int r;
-        if (leaf_ref(cc[k], r)) { who[m] = cc[k]; ref[m++] = r; continue; }
-        const int2 g = children[cc[k]];                 // an inner child at an odd depth: take its children
-        const int gg[2] = { g.x, g.y };
-        for (int q = 0; q < 2; q++) {
-            int r2;
-            who[m] = gg[q];
-            ref[m++] = leaf_ref(gg[q], r2) ? r2 : pre4[gg[q]];
+    // children in slot order: binary node (or single-triangle) ids and their references
+    int who[4], ref[4];
+    const int m = wide_children(i, children, range, n, leaf_max, who);
+    for (int k = 0; k < m; k++) {
+        const int c = who[k];
+        if (c >= n - 1) {
+            const int j = c - (n - 1);
+            ref[k] = ~(((leafpos ? leafpos[j] : j) << 3) | 0);
+        } else {
+            const int2 rg = range[c];
+            const int cnt = rg.y - rg.x + 1;
+            ref[k] = cnt <= leaf_max ? ~((rg.x << 3) | (cnt - 1)) : wide_index(c, depth, slot, pre4);
         }
     }
     unsigned int w[12];
@@ -609,7 +638,7 @@ __global__ void k_emit_wide(const int2 *__restrict__ children, const int2 *__res
     nd.b = make_uint4(w[4], w[5], w[6], w[7]);
     nd.c = make_uint4(w[8], w[9], w[10], w[11]);
     nd.d = make_uint4((unsigned)ref[0], (unsigned)ref[1], (unsigned)ref[2], (unsigned)ref[3]);
-    wnodes[pre4[i]] = nd;
+    wnodes[wide_index(i, depth, slot, pre4)] = nd;
     atomicMax(wide_depth, depth[i] / 2 + 1);
 }
 
@@ -698,7 +727,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     A(grid.alloc(1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->qnodes, sizeof(BvhNodeQ) * (size_t)(n - 1)));
-    A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * (size_t)(n - 1)));
+    A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES)));
     A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
     if (e != hipSuccess) {
         if (err) *err = std::string("lbvh_build allocation: ") + hipGetErrorString(e);
@@ -726,7 +755,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->qnodes, 0, sizeof(BvhNodeQ) * (size_t)(n - 1), stream), err);
-    RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * (size_t)(n - 1), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
     const bool ploc = builder != 1;
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
@@ -811,8 +840,18 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     for (int level = 0; level <= max_depth; level++)
         hipLaunchKernelGGL(k_wide_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, wide.p, n,
                            level, pre4.p);
+    DevBuf<int> slot;
+    if (slot.alloc(n) != hipSuccess) {
+        if (err) *err = "wide node allocation failed";
+        lbvh_free(out);
+        return RT_E_NOMEM;
+    }
+    RT_HIP_CHECK(hipMemsetAsync(slot.p, 0, sizeof(int) * (size_t)n, stream), err);
+    for (int wl = 0; wl + 1 < WIDE_TOP_LEVELS; wl++)
+        hipLaunchKernelGGL(k_wide_slots, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p, n,
+                           leaf_max, wl, slot.p);
     hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p, n, leaf_max,
-                       box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, out->wnodes, scalars.p + 2);
+                       box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, slot.p, out->wnodes, scalars.p + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);

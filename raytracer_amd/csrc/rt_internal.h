@@ -58,6 +58,11 @@ struct BvhNode4 {
     uint4 d;      // child references 0..3 (inner: wide node index; negative: leaf, as in BvhNode)
 };
 
+// The first WIDE_TOP_NODES entries of the wide node array are the top WIDE_TOP_LEVELS levels as a complete
+// 4-ary tree (unused slots zero); the traversal kernel copies them into LDS.
+constexpr int WIDE_TOP_LEVELS = 4;
+constexpr int WIDE_TOP_NODES = 1 + 4 + 16 + 64;
+
 struct QuantGrid {
     float base[3], step[3];
 };
@@ -99,7 +104,7 @@ struct FrameCounters {
 struct LbvhResult {
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
     BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
-    BvhNode4 *wnodes = nullptr;    // [max(n_tris-1,1)] (about a quarter used)
+    BvhNode4 *wnodes = nullptr;    // [WIDE_TOP_NODES + max(n_tris-1,1)] (about a quarter used)
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
     int n_nodes = 0, depth = 0, wide_depth = 0, leaf_max = 0, builder = 0;

@@ -58,11 +58,14 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_WIDE
 #define WF_WIDE 1          // traverse the 4-wide nodes (one dependent fetch per two binary levels)
 #endif
+#ifndef WF_TOP_CACHE
+#define WF_TOP_CACHE 0     // 1: keep the top levels of the wide tree in LDS (measured 5 % slower: two load paths per step)
+#endif
 #ifndef WF_MERGE
 #define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
 #endif
 #ifndef WF_WAVES_EU
-#define WF_WAVES_EU 8      // > 0: register budget for this many k_trace waves per SIMD (8 = the persistent grid's residency)
+#define WF_WAVES_EU 8      // register budget and resident blocks per CU of k_trace
 #endif
 #ifndef WF_WAVES_EU_MIXED
 #define WF_WAVES_EU_MIXED 7   // the mixed-kind kernel carries more state: 7 waves avoid spills in its loop
@@ -111,11 +114,20 @@ void k_trace(TraceArgs A)
 {
     constexpr bool ANYHIT = MODE == 1;
     __shared__ int s_stack[WF_LDS_STACK * BLOCK];
+#if WF_WIDE && WF_TOP_CACHE
+    // the top levels of the wide tree, copied once per block: every ray starts here, and the vector
+    // memory return path (not LDS) is what limits this kernel
+    __shared__ uint4 s_top[WIDE_TOP_NODES * 4];
+#endif
     const int lane = threadIdx.x & 63;
     int *stack = s_stack + threadIdx.x;                                   // element k at stack[k * BLOCK]
     int *ovf = A.overflow + (size_t)blockIdx.x * BLOCK + threadIdx.x;     // element k at ovf[k * total_lanes]
     const DevScene &sc = A.sc;
     const unsigned long long lt = lanemask_lt();
+#if WF_WIDE && WF_TOP_CACHE
+    for (int k = threadIdx.x; k < WIDE_TOP_NODES * 4; k += BLOCK) s_top[k] = ((const uint4 *)sc.wnodes)[k];
+    __syncthreads();
+#endif
 
     // ---- per-lane ray state
     int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = MODE == 0 ? -1 : 0;
@@ -251,8 +263,17 @@ void k_trace(TraceArgs A)
                 const float tmax = ANYHIT ? FLT_MAX : best_t;      // mixed: a shadow lane's best_t stays FLT_MAX
 #if WF_WIDE
                 // four children from one 64-byte node; the lattice boxes contain the padded float boxes
-                const BvhNode4 *np = sc.wnodes + node;
-                const uint4 qa = np->a, qb = np->b, qc = np->c, qd = np->d;
+                uint4 qa, qb, qc, qd;
+#if WF_TOP_CACHE
+                if (node < WIDE_TOP_NODES) {
+                    const uint4 *tp = s_top + 4 * node;
+                    qa = tp[0]; qb = tp[1]; qc = tp[2]; qd = tp[3];
+                } else
+#endif
+                {
+                    const BvhNode4 *np = sc.wnodes + node;
+                    qa = np->a; qb = np->b; qc = np->c; qd = np->d;
+                }
                 float dk[4];
                 int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
                 {
@@ -511,15 +532,15 @@ void launch_trace(const TraceArgs &a, bool count, int grid, hipStream_t stream)
 
 }  // namespace
 
-// Persistent traversal blocks per CU (8 = the LDS/VGPR residency limit).  RT_WF_BLOCKS_PER_CU
+// Persistent traversal blocks per CU (the LDS/VGPR residency limit).  RT_WF_BLOCKS_PER_CU
 // overrides it for occupancy experiments.
 int wavefront_trace_grid(int num_cus)
 {
     static int per_cu = 0;
     if (per_cu == 0) {
         const char *e = getenv("RT_WF_BLOCKS_PER_CU");
-        per_cu = e ? atoi(e) : 8;
-        if (per_cu < 1 || per_cu > 8) per_cu = 8;
+        per_cu = e ? atoi(e) : WF_WAVES_EU;
+        if (per_cu < 1 || per_cu > 8) per_cu = WF_WAVES_EU;
     }
     return num_cus * per_cu;
 }
