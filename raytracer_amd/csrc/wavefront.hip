@@ -58,6 +58,9 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_WIDE
 #define WF_WIDE 1          // traverse the 4-wide nodes (one dependent fetch per two binary levels)
 #endif
+#ifndef WF_SORT
+#define WF_SORT 0          // 0: nearest child first, the other hits in slot order (measured 2 % faster); 1: all hits sorted by entry distance
+#endif
 #ifndef WF_TOP_CACHE
 #define WF_TOP_CACHE 0     // 1: keep the top levels of the wide tree in LDS (measured 5 % slower: two load paths per step)
 #endif
@@ -289,7 +292,6 @@ void k_trace(TraceArgs A)
                     }
                 }
                 if (COUNT) tl.box += 4;
-                const int n_hit = (dk[0] < FLT_MAX) + (dk[1] < FLT_MAX) + (dk[2] < FLT_MAX) + (dk[3] < FLT_MAX);
                 // nearest first: a five-exchange sorting network on (distance, reference)
 #define WF_CSWAP(a, b)                                                          \
                 {                                                               \
@@ -301,6 +303,8 @@ void k_trace(TraceArgs A)
                     dk[a] = td;                                                 \
                     rk[a] = tr;                                                 \
                 }
+#if WF_SORT
+                const int n_hit = (dk[0] < FLT_MAX) + (dk[1] < FLT_MAX) + (dk[2] < FLT_MAX) + (dk[3] < FLT_MAX);
                 WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2) WF_CSWAP(1, 3) WF_CSWAP(1, 2)
 #undef WF_CSWAP
                 if (n_hit == 0) {
@@ -311,6 +315,28 @@ void k_trace(TraceArgs A)
                     if (n_hit > 1) push(rk[1]);
                     node = rk[0];
                 }
+#else
+                // nearest child to slot 0; the other hits are pushed in slot order
+                WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2)
+#undef WF_CSWAP
+                if (!(dk[0] < FLT_MAX)) {
+                    pop();
+                } else if (sp + 3 <= WF_LDS_STACK) {
+                    // branch-free push: every slot is stored, a miss lands on the position the next
+                    // hit (or a later push) overwrites
+                    const int c3 = dk[3] < FLT_MAX ? 1 : 0, c2 = dk[2] < FLT_MAX ? 1 : 0, c1 = dk[1] < FLT_MAX ? 1 : 0;
+                    stack[sp * BLOCK] = rk[3];
+                    stack[(sp + c3) * BLOCK] = rk[2];
+                    stack[(sp + c3 + c2) * BLOCK] = rk[1];
+                    sp += c3 + c2 + c1;
+                    node = rk[0];
+                } else {
+                    if (dk[3] < FLT_MAX) push(rk[3]);
+                    if (dk[2] < FLT_MAX) push(rk[2]);
+                    if (dk[1] < FLT_MAX) push(rk[1]);
+                    node = rk[0];
+                }
+#endif
 #else
                 // ---- both children's lattice boxes from one 32-byte node
                 const BvhNodeQ *np = sc.qnodes + node;
