@@ -193,6 +193,39 @@ def test_band_partition_on_device_and_deinterleave():
             assert np.array_equal(gathered_id[p, : len(ys)].cpu().numpy(), full["hit_id"][ys])
 
 
+def test_band_partition_of_an_lbvh_scene_matches_the_whole_frame():
+    """The staged LBVH pipeline on every rank's band set (what bench.py runs on N GPUs), reassembled,
+    equals the single-GPU frame bit for bit; odd height so that the last band is partial."""
+    import torch
+    spec = atrium_spec(detail=0.02)
+    W, H, bounces, parts, band = 200, 150, 3, 4, 16
+    cam = rt.camera_for_width(W)
+    cap = rt.rows_per_part(H, band, parts)
+    with rt.Context(0) as ctx:
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        full = ctx.render_frame(W, H, max_depth=bounces)
+        full_rays = rays(ctx.stats())
+        assert ctx.stats()["accel"] == 1
+        g8 = torch.zeros((parts, cap, W, 3), dtype=torch.uint8, device="cuda")
+        gid = torch.full((parts, cap, W), -7, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        total = [0, 0, 0]
+        for p in range(parts):
+            rs = rt.band_rowset(H, band, p, parts)
+            ctx.render_rows_device(W, H, rs, bounces, g8[p].data_ptr(), gid[p].data_ptr(), None, None, stream)
+            torch.cuda.synchronize()
+            total = [a + b for a, b in zip(total, rays(ctx.stats()))]
+        out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        outid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        ctx.deinterleave_bands(g8.data_ptr(), out8.data_ptr(), W, H, band, parts, cap, 3, stream)
+        ctx.deinterleave_bands(gid.data_ptr(), outid.data_ptr(), W, H, band, parts, cap, 4, stream)
+        torch.cuda.synchronize()
+    assert np.array_equal(out8.cpu().numpy(), full["rgb8"])
+    assert np.array_equal(outid.cpu().numpy(), full["hit_id"])
+    assert tuple(total) == full_rays                       # the parts cast exactly the frame's rays
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
