@@ -61,6 +61,9 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_SORT
 #define WF_SORT 0          // 0: nearest child first, the other hits in slot order (measured 2 % faster); 1: all hits sorted by entry distance
 #endif
+#ifndef WF_CLOSEST_FIRST
+#define WF_CLOSEST_FIRST 1
+#endif
 #ifndef WF_TOP_CACHE
 #define WF_TOP_CACHE 0     // 1: keep the top levels of the wide tree in LDS (measured 5 % slower: two load paths per step)
 #endif
@@ -192,6 +195,10 @@ void k_trace(TraceArgs A)
                 const unsigned int u = (unsigned)unit;
                 const unsigned int per_seg = (unsigned)A.n_regions * UPR;
                 seg = (int)(u / per_seg);
+#if WF_CLOSEST_FIRST
+                // mixed launch: the nearest-hit rays are claimed first, the shadow rays fill the end of the launch
+                if (MODE == 2) seg = seg == 0 ? A.n_segments : seg - 1;
+#endif
                 const unsigned int rem = u % per_seg, region = rem / UPR, sub = rem % UPR;
                 unsigned int cnt;
                 if (PRIMARY) {
