@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch of every frame instead of replaying a hipGraph")
     ap.add_argument("--builder", type=int, default=0, help="0 auto, 1 Karras LBVH, 2 PLOC")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto, 1 fused bounce kernel, 2 wavefront stages")
     return ap.parse_args()
@@ -113,6 +114,8 @@ def main():
         ctx.set_option(rt.OPT_PIPELINE, a.pipeline)
     if a.builder:
         ctx.set_option(rt.OPT_BUILDER, a.builder)
+    if a.no_graph:
+        ctx.set_option(rt.OPT_GRAPH, 0)
     wl.load(ctx)
     pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
 
@@ -122,6 +125,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the timed loop runs without per-launch device events, so that an unchanged frame replays as one
+    # hipGraph; kernel times come from one more frame with the events on, outside the timed region
+    ctx.set_option(rt.OPT_TIMING, 0)
     for _ in range(a.warmup):
         pr.render()
     sync_all()
@@ -130,7 +136,10 @@ def main():
         pr.render()
     sync_all()
     dt = time.perf_counter() - t0
-    st = ctx.stats()   # last frame of this rank: ray counts + device-event kernel times
+    ctx.set_option(rt.OPT_TIMING, 1)
+    pr.render()
+    sync_all()
+    st = ctx.stats()   # one frame of this rank: ray counts + device-event kernel times
 
     rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
     vec = torch.tensor([dt, float(rays_local), float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"]),

@@ -37,6 +37,11 @@ struct rt_ctx {
     int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0;
     DevCamera cam;
     FrameWorkspace ws;
+    // replay of the last frame's launches (RT_OPT_GRAPH, only with timing and test counting off)
+    int opt_graph = 1;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<unsigned char> graph_key;
+    unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
     // last frame
     bool frame_valid = false;
     int last_levels = 0, last_launches = 0, last_accel = 0;
@@ -77,8 +82,16 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+void drop_graph(rt_ctx *c)
+{
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+    c->graph_key.clear();
+}
+
 void free_triangles(rt_ctx *c)
 {
+    c->state_version++;
     if (c->d_tri_mt) (void)hipFree(c->d_tri_mt);
     if (c->d_tri_n) (void)hipFree(c->d_tri_n);
     if (c->d_mats) (void)hipFree(c->d_mats);
@@ -306,7 +319,53 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
     std::string err;
     int launches = 0;
-    int rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+    int rc = RT_OK;
+    const bool want_graph = c->opt_graph && !fp.timing && !fp.count_tests;
+    if (want_graph) {
+        // The launches of a frame depend only on these values: when none changed since the last frame,
+        // replay the captured graph instead of issuing a dozen launches one by one.
+        struct Key {
+            FrameParams fp; DevScene sc; DevCamera cam; void *out[4]; void *ws[18]; unsigned long long version;
+        } key;
+        memset(&key, 0, sizeof key);
+        key.fp = fp; key.sc = sc; key.cam = c->cam;
+        key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
+        void *wsp[18] = { c->ws.records, c->ws.queue_o[0], c->ws.queue_o[1], c->ws.queue_d[0], c->ws.queue_d[1], c->ws.counters,
+                          c->ws.p_hits, c->ws.p_occ, c->ws.sq_o, c->ws.sq_d, c->ws.trace_cursors, c->ws.overflow,
+                          c->ws.rq_counts[0], c->ws.rq_counts[1], c->ws.sq_counts, c->ws.ls_o, c->ws.ls_d, c->ws.hit_t };
+        memcpy(key.ws, wsp, sizeof wsp);
+        key.version = c->state_version;
+        const bool same = c->graph_exec && c->graph_key.size() == sizeof key && memcmp(c->graph_key.data(), &key, sizeof key) == 0;
+        if (!same) {
+            drop_graph(c);
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, c->stream, &launches, &err);
+                const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+                if (rc == RT_OK && ee == hipSuccess && graph &&
+                    hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    c->graph_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
+                    c->last_launches = launches;
+                } else {
+                    c->graph_exec = nullptr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+            }
+            if (rc != RT_OK) return fail(rc, err);
+        }
+        if (c->graph_exec) {
+            if (hipGraphLaunch(c->graph_exec, stream) != hipSuccess) {
+                drop_graph(c);
+                return fail(RT_E_DEVICE, "hipGraphLaunch failed");
+            }
+            launches = c->last_launches;
+        } else {
+            rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+        }
+    } else {
+        rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+    }
     if (rc != RT_OK) return fail(rc, err);
     c->frame_valid = true;
     c->last_levels = max_depth + 1;
@@ -355,6 +414,7 @@ void rt_destroy(rt_ctx *c)
     if (!c) return;
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     free_triangles(c);
     free_workspace(c->ws);
     if (c->d_analytic) (void)hipFree(c->d_analytic);
@@ -381,6 +441,7 @@ int rt_set_option(rt_ctx *c, int option, int value)
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_BUILDER takes 0, 1 or 2");
         c->opt_builder = value;
         return RT_OK;
+    case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graph(c); return RT_OK;
     case RT_OPT_PIPELINE:
         if (value < 0 || value > 3) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0..3");
         c->opt_pipeline = value;

@@ -226,6 +226,48 @@ def test_band_partition_of_an_lbvh_scene_matches_the_whole_frame():
     assert tuple(total) == full_rays                       # the parts cast exactly the frame's rays
 
 
+def test_graph_replay_of_an_unchanged_frame_and_recapture_after_a_change():
+    """With timing off an unchanged frame replays a captured hipGraph: same bytes as the direct launches,
+    also after the camera, the depth and the scene change (each forces a new capture)."""
+    import torch
+    spec = atrium_spec(detail=0.02)
+    W, H = 160, 120
+    rs = rt.RowSet(0, 1, 1, H)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def frame(ctx, depth):
+        out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        ids = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        res = []
+        for _ in range(3):                                   # first call captures, the next two replay
+            out.zero_(); ids.zero_()
+            ctx.render_rows_device(W, H, rs, depth, out.data_ptr(), ids.data_ptr(), None, None, stream)
+            torch.cuda.synchronize()
+            res.append((out.cpu().numpy().copy(), ids.cpu().numpy().copy(), rays(ctx.stats())))
+        for r in res[1:]:
+            assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and r[2] == res[0][2]
+        return res[0]
+
+    results = {}
+    for graph in (0, 1):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_TIMING, 0)
+            ctx.set_option(rt.OPT_GRAPH, graph)
+            to_product(ctx, spec)
+            ctx.set_camera(rt.camera_for_width(W))
+            a = frame(ctx, 3)
+            ctx.set_camera(rt.Camera(origin=(0.5, 0.0, -5.0), pitch=8.0 / W, off_x=-3.5))
+            b = frame(ctx, 3)
+            c = frame(ctx, 1)
+            to_product(ctx, cube_spec(mirror=False, mesh_reflect=0.5))   # another scene, linear-scan path
+            ctx.set_camera(rt.camera_for_width(W))
+            d = frame(ctx, 2)
+            results[graph] = (a, b, c, d)
+    for x, y in zip(results[0], results[1]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+    assert not np.array_equal(results[1][0][0], results[1][1][0])        # the camera move is visible
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
