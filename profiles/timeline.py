@@ -1,15 +1,16 @@
-"""Print the kernel timeline of the last frame from a rocprofv3 --kernel-trace csv directory:
-start offset, duration and gap to the previous kernel's end (all in microseconds)."""
+"""Print the kernel timeline of the last full frame from a rocprofv3 --kernel-trace csv directory:
+start offset, duration and gap to the previous kernel's end (all in microseconds).  A frame starts at a
+camera-ray launch (k_trace<0, true, ...> or k_bounce<..., true, ...>)."""
 import csv, glob, os, sys
 
 def main(d):
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    # last frame = from the last level-0 primary k_trace to the end
     names = [r["Kernel_Name"] for r in rows]
-    starts = [i for i, n in enumerate(names) if "k_trace<false, true" in n]
-    i0 = starts[-2] if len(starts) > 1 else starts[-1]
-    i1 = starts[-1] if len(starts) > 1 else len(rows)
+    starts = [i for i, n in enumerate(names) if "k_trace<0, true" in n or ("k_bounce<" in n and ", true, " in n.split("k_bounce<")[1][:12])]
+    if len(starts) < 2:
+        print("no complete frame found"); return
+    i0, i1 = starts[-2], starts[-1]
     t0 = int(rows[i0]["Start_Timestamp"]); prev_end = t0
     for r in rows[i0:i1]:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

@@ -144,6 +144,7 @@ struct FrameWorkspace {
     // wavefront pipeline (LBVH scenes)
     float4 *sq_o = nullptr, *sq_d = nullptr;   // [seg_cap][slots_cap] shadow rays, one segment per light of a chunk
     unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue
+    unsigned int *fq_counts[2] = { nullptr, nullptr };   // fused kernel: rays per 64-slot batch of each ray queue
     unsigned int *sq_counts = nullptr;         // [seg_cap][regions] shadow rays per segment and region
     unsigned int *trace_cursors = nullptr;     // per-frame unit claim cursors, one row per k_trace launch
     int *overflow = nullptr;       // traversal stack spill columns

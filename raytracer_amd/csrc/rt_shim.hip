@@ -106,7 +106,7 @@ void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
                      ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
-                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d };
+                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -127,10 +127,10 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
     if (qslots > ws.pixels_cap || levels > ws.levels_cap) {
         size_t pc = qslots > ws.pixels_cap ? qslots : ws.pixels_cap;
         int lc = levels > ws.levels_cap ? levels : ws.levels_cap;
-        void *old[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1] };
+        void *old[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.fq_counts[0], ws.fq_counts[1] };
         for (void *p : old)
             if (p) (void)hipFree(p);
-        ws.records = nullptr; ws.hit_t = nullptr;
+        ws.records = nullptr; ws.hit_t = nullptr; ws.fq_counts[0] = ws.fq_counts[1] = nullptr;
         ws.queue_o[0] = ws.queue_o[1] = ws.queue_d[0] = ws.queue_d[1] = nullptr;
         ws.pixels_cap = 0; ws.levels_cap = 0;
         hipError_t e = hipMalloc((void **)&ws.records, sizeof(float4) * pc * (size_t)lc);
@@ -138,6 +138,7 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         for (int k = 0; k < 2 && e == hipSuccess; k++) {
             e = hipMalloc((void **)&ws.queue_o[k], sizeof(float4) * pc);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.queue_d[k], sizeof(float4) * pc);
+            if (e == hipSuccess) e = hipMalloc((void **)&ws.fq_counts[k], sizeof(unsigned int) * (pc / 64 + 1));
         }
         if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("frame workspace: ") + hipGetErrorString(e));
         ws.pixels_cap = pc;

@@ -148,6 +148,9 @@ struct BounceArgs {
     float *hit_t;                    // level 0 only, may be null
     const float4 *q_in_o, *q_in_d;   // level > 0
     float4 *q_out_o, *q_out_d;
+    const unsigned int *counts_in;    // level > 0: rays in each 64-slot batch of the input queue
+    unsigned int *counts_out;         // rays this launch leaves in each batch of the output queue
+    unsigned int n_batches;
     FrameCounters *counters;
     int stack_cap;
 };
@@ -159,16 +162,21 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
     int *stack = s_stack + threadIdx.x;
     const DevScene &sc = A.sc;
     const int lane = threadIdx.x & 63;
-    const unsigned int n = PRIMARY ? A.n_slots : A.counters->queue_count[A.level];
     Tally tl = { 0u, 0u, 0u };
-    unsigned int n_shadow = 0, n_reflect = 0;
+    // Batches of 64 slots are dealt to the waves statically, and the rays a batch spawns go to the same
+    // batch of the next level's queue (dense from its first slot, with a count): no cursor and no queue
+    // tail to contend for — atomics on one address retire at ~90 per microsecond on this chip, which
+    // would cost more than the whole linear scan of a small scene.
+    const unsigned int wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (BLOCK / 64);
+    const bool more = A.level < A.max_depth;
 
-    for (;;) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&A.counters->cursor[A.level], 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const unsigned int slot = base + (unsigned)lane;
+    for (unsigned int batch = wave_id; batch < A.n_batches; batch += n_waves) {
+        const unsigned int cnt = PRIMARY ? 64u : A.counts_in[batch];
+        if (cnt == 0u) {
+            if (more && lane == 0) A.counts_out[batch] = 0u;
+            continue;
+        }
+        const unsigned int slot = batch * 64u + (unsigned)lane;
 
         // ---- this lane's ray
         bool live;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             float offsetY = (float)y * A.cam.pitch + A.cam.off_y;               // main.cpp:269
             d = normalize(sub(mk(offsetX, offsetY, A.cam.plane_z), o));         // main.cpp:270
         } else {
-            live = slot < n;
+            live = (unsigned)lane < cnt;
             float4 qo = live ? A.q_in_o[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 qd = live ? A.q_in_d[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
             o = f3(qo);
@@ -233,7 +241,6 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
         F3 col = mk(0.f, 0.f, 0.f);
         const bool lit = hit && !emissive;
         if (hit && emissive) col = Mc;                                          // main.cpp:166-167
-        if (lit) n_shadow += (unsigned)sc.n_lights;
         for (int li = 0; li < sc.n_lights; li++) {                              // main.cpp:170-173
             const DevAnalytic lt = sc.analytic[sc.lights[li]];
             F3 L = mk(0.f, 0.f, 1.f), so = pos;
@@ -271,34 +278,25 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
                 make_float4(col.x, col.y, col.z, __int_as_float(best_id));
             if (PRIMARY && A.hit_t) A.hit_t[pixel] = best_t;
         }
-        const bool spawn = lit && kr > 0.0f && A.level < A.max_depth;
+        const bool spawn = lit && kr > 0.0f && more;
         const unsigned long long mask = __ballot(spawn);
-        if (mask) {
-            unsigned int qbase = 0;
-            if (lane == 0) qbase = atomicAdd(&A.counters->queue_count[A.level + 1], (unsigned)__popcll(mask));
-            qbase = __shfl(qbase, 0);
-            if (spawn) {
-                F3 R = sub(d, muls(muls(N, 2.0f), dot(d, N)));                  // main.cpp:210
-                unsigned int dst = qbase + (unsigned)__popcll(mask & lanemask_lt());
-                A.q_out_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(pixel));   // origin is pos itself
-                A.q_out_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
-                n_reflect++;
-            }
+        if (spawn) {
+            F3 R = sub(d, muls(muls(N, 2.0f), dot(d, N)));                      // main.cpp:210
+            const unsigned int dst = batch * 64u + (unsigned)__popcll(mask & lanemask_lt());
+            A.q_out_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(pixel));       // origin is pos itself
+            A.q_out_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
         }
+        if (more && lane == 0) A.counts_out[batch] = (unsigned)__popcll(mask);
     }
 
-    // ---- ray / test counters: wave reduce, one atomic per wave
-    unsigned int vals[5] = { n_shadow, n_reflect, tl.box, tl.tri, tl.analytic };
-    const int nv = COUNT ? 5 : 2;
-    for (int k = 0; k < nv; k++) {
-        unsigned long long v = vals[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0 && v) {
-            unsigned long long *dst = k == 0 ? &A.counters->rays_shadow
-                                    : k == 1 ? &A.counters->rays_reflect
-                                    : k == 2 ? &A.counters->box_tests
-                                    : k == 3 ? &A.counters->tri_tests : &A.counters->analytic_tests;
-            atomicAdd(dst, v);
+    // ---- test counters (COUNT builds): wave reduce, one atomic per wave.  Ray counts come from k_resolve.
+    if (COUNT) {
+        unsigned int vals[3] = { tl.box, tl.tri, tl.analytic };
+        for (int k = 0; k < 3; k++) {
+            unsigned long long v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v)
+                atomicAdd(k == 0 ? &A.counters->box_tests : k == 1 ? &A.counters->tri_tests : &A.counters->analytic_tests, v);
         }
     }
 }
@@ -311,6 +309,7 @@ struct ResolveArgs {
     uint8_t *rgb8;      // may be null
     int32_t *hit_id;    // may be null
     float *rgb32;       // may be null
+    FrameCounters *counters;
 };
 
 __device__ __forceinline__ float clamp01(float f) { return f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f); }   // main.cpp:139-142
@@ -325,48 +324,66 @@ __device__ __forceinline__ uint8_t quantise(float c)
 
 __global__ __launch_bounds__(BLOCK) void k_resolve(ResolveArgs A)
 {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= A.n_pixels) return;
+    __shared__ unsigned int s_stat[2];
     const DevScene &sc = A.sc;
-    // Find the deepest level that exists for this pixel: a level k+1 record exists
-    // iff the level-k hit reflected (same test as the spawn in k_bounce).
-    int last = 0;
-    int id0 = -1;
-    for (int k = 0;; k++) {
-        float4 r = A.records[(size_t)k * (size_t)A.n_pixels + (size_t)p];
-        int id = __float_as_int(r.w);
-        if (k == 0) id0 = id;
-        last = k;
-        if (id < 0 || k >= A.max_depth) break;
-        float kr;
-        bool emissive;
-        if (id < sc.n_analytic) { kr = sc.analytic[id].reflect; emissive = sc.analytic[id].is_light != 0; }
-        else { kr = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)].reflect; emissive = false; }
-        if (emissive || !(kr > 0.0f)) break;
-    }
-    float4 r = A.records[(size_t)last * (size_t)A.n_pixels + (size_t)p];
-    F3 col = mk(r.x, r.y, r.z);
-    for (int k = last - 1; k >= 0; k--) {
-        float4 rk = A.records[(size_t)k * (size_t)A.n_pixels + (size_t)p];
-        int id = __float_as_int(rk.w);
-        F3 Mc;
-        float kr;
-        if (id < sc.n_analytic) {
-            const DevAnalytic a = sc.analytic[id];
-            Mc = mk(a.cr, a.cg, a.cb); kr = a.reflect;
-        } else {
-            const DevMaterial m = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)];
-            Mc = mk(m.cr, m.cg, m.cb); kr = m.reflect;
+    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int n_shadow = 0, n_reflect = 0;
+    for (size_t p = (size_t)blockIdx.x * BLOCK + threadIdx.x; p < (size_t)A.n_pixels; p += (size_t)gridDim.x * BLOCK) {
+        // Find the deepest level that exists for this pixel: a level k+1 record exists
+        // iff the level-k hit reflected (same test as the spawn in k_bounce).  Every hit that is
+        // not a light cast one shadow ray per light (main.cpp:170-188).
+        int last = 0;
+        int id0 = -1;
+        for (int k = 0;; k++) {
+            float4 r = A.records[(size_t)k * (size_t)A.n_pixels + p];
+            int id = __float_as_int(r.w);
+            if (k == 0) id0 = id;
+            last = k;
+            if (id < 0) break;
+            float kr;
+            bool emissive;
+            if (id < sc.n_analytic) { kr = sc.analytic[id].reflect; emissive = sc.analytic[id].is_light != 0; }
+            else { kr = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)].reflect; emissive = false; }
+            if (emissive) break;
+            n_shadow += (unsigned)sc.n_lights;
+            if (!(kr > 0.0f) || k >= A.max_depth) break;
+            n_reflect++;
         }
-        col = add(mk(rk.x, rk.y, rk.z), muls(mulv(col, Mc), kr));               // main.cpp:212
+        float4 r = A.records[(size_t)last * (size_t)A.n_pixels + p];
+        F3 col = mk(r.x, r.y, r.z);
+        for (int k = last - 1; k >= 0; k--) {
+            float4 rk = A.records[(size_t)k * (size_t)A.n_pixels + p];
+            int id = __float_as_int(rk.w);
+            F3 Mc;
+            float kr;
+            if (id < sc.n_analytic) {
+                const DevAnalytic a = sc.analytic[id];
+                Mc = mk(a.cr, a.cg, a.cb); kr = a.reflect;
+            } else {
+                const DevMaterial m = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)];
+                Mc = mk(m.cr, m.cg, m.cb); kr = m.reflect;
+            }
+            col = add(mk(rk.x, rk.y, rk.z), muls(mulv(col, Mc), kr));               // main.cpp:212
+        }
+        if (A.rgb32) { A.rgb32[3 * p] = col.x; A.rgb32[3 * p + 1] = col.y; A.rgb32[3 * p + 2] = col.z; }
+        if (A.rgb8) {                                                               // main.cpp:273
+            A.rgb8[3 * p] = quantise(col.x);
+            A.rgb8[3 * p + 1] = quantise(col.y);
+            A.rgb8[3 * p + 2] = quantise(col.z);
+        }
+        if (A.hit_id) A.hit_id[p] = id0;
     }
-    if (A.rgb32) { A.rgb32[3 * (size_t)p] = col.x; A.rgb32[3 * (size_t)p + 1] = col.y; A.rgb32[3 * (size_t)p + 2] = col.z; }
-    if (A.rgb8) {                                                               // main.cpp:273
-        A.rgb8[3 * (size_t)p] = quantise(col.x);
-        A.rgb8[3 * (size_t)p + 1] = quantise(col.y);
-        A.rgb8[3 * (size_t)p + 2] = quantise(col.z);
+    // ray counters: wave reduce -> LDS -> one atomic per block and counter
+    unsigned int vals[2] = { n_shadow, n_reflect };
+    for (int k = 0; k < 2; k++) {
+        unsigned int v = vals[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[k], v);
     }
-    if (A.hit_id) A.hit_id[p] = id0;
+    __syncthreads();
+    if (threadIdx.x < 2 && s_stat[threadIdx.x])
+        atomicAdd(threadIdx.x == 0 ? &A.counters->rays_shadow : &A.counters->rays_reflect, (unsigned long long)s_stat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ band de-interleave (after the gather)
@@ -479,11 +496,12 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
         a.q_in_d = ws.queue_d[level & 1];
         a.q_out_o = ws.queue_o[(level + 1) & 1];
         a.q_out_d = ws.queue_d[(level + 1) & 1];
+        a.counts_in = ws.fq_counts[level & 1];
+        a.counts_out = ws.fq_counts[(level + 1) & 1];
+        a.n_batches = a.n_slots / 64u;
         int grid = full_grid;
-        if (level == 0) {
-            int need = (int)((a.n_slots + BLOCK - 1) / BLOCK);
-            if (need < grid) grid = need;
-        }
+        const int need = (int)((a.n_slots + BLOCK - 1) / BLOCK);
+        if (need < grid) grid = need;
         const bool primary = level == 0, count = fp.count_tests != 0;
         if (scene.accel == 1) {
             if (fp.stack_depth <= 32) launch_bounce_sel<1, 32>(a, primary, count, grid, stream);
@@ -502,7 +520,10 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     r.rgb8 = (uint8_t *)d_rgb8;
     r.hit_id = (int32_t *)d_hit_id;
     r.rgb32 = (float *)d_rgb32;
-    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, r);
+    r.counters = ws.counters;
+    int rgrid = (n_pixels + BLOCK - 1) / BLOCK;
+    if (rgrid > g_num_cus * 8) rgrid = g_num_cus * 8;
+    hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(BLOCK), 0, stream, r);
     launches++;
     if (int rc = stamp()) return rc;
     RT_HIP_CHECK(hipGetLastError(), err);
