@@ -346,10 +346,12 @@ struct ShadeAllArgs {
     FrameCounters *counters;
 };
 
-__device__ __forceinline__ uint8_t quantise8(float c)                   // main.cpp:139-142, 273
+// (char)(clamp01(c)*255.0f) as the reference's Debug build evaluates it (main.cpp:139-142, 273):
+// truncate toward zero, keep the low byte; NaN passes the clamp and converts to the low byte of INT_MIN = 0.
+__device__ __forceinline__ uint8_t quantise8(float c)
 {
-    const float f = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
-    return (uint8_t)(int)(f * 255.0f);
+    const float f = (c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c)) * 255.0f;
+    return (f == f) ? (uint8_t)(int)f : (uint8_t)0;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
