@@ -151,6 +151,19 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 int rt_render_frame(rt_ctx *ctx, int W, int H, int y0, int y1, int max_depth,
                     uint8_t *rgb8, int32_t *hit_id, float *rgb32);
 
+/* The same frame with two more planes for tooling (replaces nothing in the reference, which keeps only
+ * the 8-bit colour, Raytracer/main.cpp:273): hit_t = the camera ray's nearest t (FLT_MAX on a miss,
+ * main.cpp:147-156), normal = GetNormal at that hit (main.cpp:164; 0,0,0 on a miss), 3 floats per
+ * pixel.  Any pointer may be NULL.  Synchronous; host buffers; rows in buffer order like rt_render_frame. */
+typedef struct rt_frame_planes {
+    uint8_t *rgb8;
+    int32_t *hit_id;
+    float *rgb32;
+    float *hit_t;
+    float *normal;
+} rt_frame_planes;
+int rt_render_frame_planes(rt_ctx *ctx, int W, int H, int y0, int y1, int max_depth, const rt_frame_planes *out);
+
 /* Same work with DEVICE output buffers and an explicit HIP stream (hipStream_t as
  * void*, NULL = the context's own stream).  Asynchronous: returns after enqueueing.
  * hit_t (optional) receives the primary ray's nearest t (FLT_MAX on a miss). */

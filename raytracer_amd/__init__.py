@@ -27,7 +27,7 @@ RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48
 ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_option", "rt_set_analytic",
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
-    "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize",
+    "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
 )
 
 
@@ -64,6 +64,10 @@ class Camera(C.Structure):
 
 class RowSet(C.Structure):
     _fields_ = [("first_band", C.c_int32), ("band_rows", C.c_int32), ("band_stride", C.c_int32), ("n_rows", C.c_int32)]
+
+
+class FramePlanes(C.Structure):
+    _fields_ = [("rgb8", C.c_void_p), ("hit_id", C.c_void_p), ("rgb32", C.c_void_p), ("hit_t", C.c_void_p), ("normal", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -160,6 +164,7 @@ def load_library():
     L.rt_set_triangle_materials.argtypes = [vp, C.POINTER(Material), i32, vp, i32]
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rt_render_frame.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.rt_render_frame_planes.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(FramePlanes)]
     L.rt_render_rows_device.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
     L.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -238,6 +243,17 @@ class Context:
         ptr = lambda a: a.ctypes.data if a is not None and a.size else None
         self._check(self.L.rt_render_frame(self._h, W, H, y0, y1, max_depth, ptr(rgb8), ptr(hid), ptr(rgb32)))
         return dict(rgb8=rgb8, hit_id=hid, rgb32=rgb32)
+
+    def render_frame_planes(self, W, H, y0=0, y1=None, max_depth=3):
+        """rt_render_frame_planes: colour, id, float colour, nearest t and normal of the primary hit."""
+        y1 = H if y1 is None else y1
+        rows = max(y1 - y0, 0)
+        out = dict(rgb8=np.zeros((rows, W, 3), np.uint8), hit_id=np.full((rows, W), -2, np.int32),
+                   rgb32=np.zeros((rows, W, 3), np.float32), hit_t=np.zeros((rows, W), np.float32),
+                   normal=np.zeros((rows, W, 3), np.float32))
+        fp = FramePlanes(*[out[k].ctypes.data if out[k].size else None for k in ("rgb8", "hit_id", "rgb32", "hit_t", "normal")])
+        self._check(self.L.rt_render_frame_planes(self._h, W, H, y0, y1, max_depth, C.byref(fp)))
+        return out
 
     def render_rows_device(self, W, H, rowset, max_depth, d_rgb8=None, d_hit_id=None, d_rgb32=None, d_hit_t=None,
                            stream=None):

@@ -342,7 +342,7 @@ struct ShadeAllArgs {
     const unsigned int *occ;          // [level][chunk][pixel], 32 lights per chunk
     int n_chunks;
     float4 *records;                  // [level][pixel] scratch: (local colour, hit id bits)
-    uint8_t *rgb8; int32_t *hit_id; float *rgb32; float *hit_t;
+    uint8_t *rgb8; int32_t *hit_id; float *rgb32; float *hit_t; float *normal;
     FrameCounters *counters;
 };
 
@@ -374,7 +374,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
             const float t = h.x;
             int id = __float_as_int(h.y);
             if (id >= sc.n_analytic + sc.n_tris) id = -1;      // never index scene arrays with an id outside the scene
-            if (k == 0) { id0 = id; if (A.hit_t) A.hit_t[p] = t; }
+            if (k == 0) {
+                id0 = id;
+                if (A.hit_t) A.hit_t[p] = t;
+                if (A.normal && id < 0) { A.normal[3 * p] = 0.f; A.normal[3 * p + 1] = 0.f; A.normal[3 * p + 2] = 0.f; }
+            }
             last = k;
             F3 col = mk(0.f, 0.f, 0.f);                                                   // main.cpp:159-160
             bool spawn = false;
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
             if (id >= 0) {
                 pos = add(o, muls(d, t));                                                 // main.cpp:163
                 const Surface s = surface_at(sc, id, pos);                                // main.cpp:164
+                if (k == 0 && A.normal) { A.normal[3 * p] = s.N.x; A.normal[3 * p + 1] = s.N.y; A.normal[3 * p + 2] = s.N.z; }
                 if (s.emissive) {
                     col = s.Mc;                                                           // main.cpp:166-167
                 } else {
@@ -468,6 +473,7 @@ int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FramePar
     s.rows = fp.rows;
     s.hits = hits; s.occ = occ; s.n_chunks = n_chunks; s.records = records;
     s.rgb8 = (uint8_t *)d_rgb8; s.hit_id = (int32_t *)d_hit_id; s.rgb32 = (float *)d_rgb32; s.hit_t = (float *)d_hit_t;
+    s.normal = fp.d_normal;
     s.counters = counters;
     int sgrid = (s.n_pixels + BLOCK - 1) / BLOCK;
     if (sgrid > num_cus * 8) sgrid = num_cus * 8;

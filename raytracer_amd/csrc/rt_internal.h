@@ -131,6 +131,7 @@ struct FrameParams {
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
     int wide_depth;                // depth of the 4-wide tree
     int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages, 3 single traversal launch
+    float *d_normal;               // optional device plane: the primary hit's normal, 3 floats per pixel (0 on a miss)
 };
 
 struct FrameWorkspace {
@@ -157,7 +158,7 @@ struct FrameWorkspace {
     float4 *ls_o = nullptr, *ls_d = nullptr;   // [waves][ls_entries] private ray stacks
     size_t p_cap = 0, ls_cap = 0;  // elements allocated in p_hits / p_occ and in ls_o / ls_d
     // staging outputs for the host-buffer entry point
-    uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr;
+    uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr; float *out_normal = nullptr;
     size_t out_cap = 0;
     std::vector<hipEvent_t> events;        // frame start, after each traversal stage, after the final fold
     int n_events = 0;                      // events recorded by the last frame

@@ -105,7 +105,7 @@ void free_triangles(rt_ctx *c)
 void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
-                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
                      ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -232,13 +232,14 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         }
     }
     if (host_outputs && pixels > ws.out_cap) {
-        void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32 };
+        void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal };
         for (void *p : old)
             if (p) (void)hipFree(p);
-        ws.out_rgb8 = nullptr; ws.out_id = nullptr; ws.out_rgb32 = nullptr; ws.out_cap = 0;
+        ws.out_rgb8 = nullptr; ws.out_id = nullptr; ws.out_rgb32 = nullptr; ws.out_normal = nullptr; ws.out_cap = 0;
         hipError_t e = hipMalloc((void **)&ws.out_rgb8, 3 * pixels);
         if (e == hipSuccess) e = hipMalloc((void **)&ws.out_id, sizeof(int32_t) * pixels);
         if (e == hipSuccess) e = hipMalloc((void **)&ws.out_rgb32, sizeof(float) * 3 * pixels);
+        if (e == hipSuccess) e = hipMalloc((void **)&ws.out_normal, sizeof(float) * 3 * pixels);
         if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("output staging: ") + hipGetErrorString(e));
         ws.out_cap = pixels;
     }
@@ -290,7 +291,7 @@ int validate_rows(int W, int H, const rt_rowset *r)
 }
 
 int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
-                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs)
+                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false)
 {
     if (int rc = validate_rows(W, H, rows)) return rc;
     if (max_depth < 0 || max_depth > RT_MAX_DEPTH) return fail(RT_E_INVALID, "max_depth out of range");
@@ -317,7 +318,13 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     fp.stack_depth = accel ? c->bvh.depth : 0;
     fp.wide_depth = accel ? c->bvh.wide_depth : 0;
     fp.pipeline = c->opt_pipeline;
+    fp.d_normal = nullptr;
     if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
+    if (host_aov) {
+        if (!c->ws.out_normal || c->ws.out_cap < pixels) return fail(RT_E_STATE, "plane staging missing");
+        d_hit_t = c->ws.hit_t;
+        fp.d_normal = c->ws.out_normal;
+    }
     std::string err;
     int launches = 0;
     int rc = RT_OK;
@@ -621,6 +628,29 @@ int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint
         if (e == hipSuccess && rgb32)
             e = hipMemcpyAsync(rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels, hipMemcpyDeviceToHost, c->stream);
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, const rt_frame_planes *out)
+{
+    if (!c || !out) return fail(RT_E_INVALID, "null argument");
+    if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
+    DeviceGuard g(c->device);
+    rt_rowset rows = { y0, 1, 1, y1 - y0 };
+    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true, true);
+    if (rc != RT_OK) return rc;
+    const size_t pixels = (size_t)W * (size_t)(y1 - y0);
+    hipError_t e = hipSuccess;
+    auto pull = [&](void *dst, const void *src, size_t bytes) {
+        if (e == hipSuccess && dst && pixels) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    };
+    pull(out->rgb8, c->ws.out_rgb8, 3 * pixels);
+    pull(out->hit_id, c->ws.out_id, sizeof(int32_t) * pixels);
+    pull(out->rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels);
+    pull(out->hit_t, c->ws.hit_t, sizeof(float) * pixels);
+    pull(out->normal, c->ws.out_normal, sizeof(float) * 3 * pixels);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
     return RT_OK;

@@ -146,6 +146,7 @@ struct BounceArgs {
     unsigned int n_slots;            // level 0: padded 8x8-tile slot count
     float4 *records;                 // [level][pixel]
     float *hit_t;                    // level 0 only, may be null
+    float *normal;                   // level 0 only, may be null
     const float4 *q_in_o, *q_in_d;   // level > 0
     float4 *q_out_o, *q_out_d;
     const unsigned int *counts_in;    // level > 0: rays in each 64-slot batch of the input queue
@@ -277,6 +278,10 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             A.records[(size_t)A.level * (size_t)A.n_pixels + (size_t)pixel] =
                 make_float4(col.x, col.y, col.z, __int_as_float(best_id));
             if (PRIMARY && A.hit_t) A.hit_t[pixel] = best_t;
+            if (PRIMARY && A.normal) {
+                const F3 Nn = hit ? N : mk(0.f, 0.f, 0.f);
+                A.normal[3 * (size_t)pixel] = Nn.x; A.normal[3 * (size_t)pixel + 1] = Nn.y; A.normal[3 * (size_t)pixel + 2] = Nn.z;
+            }
         }
         const bool spawn = lit && kr > 0.0f && more;
         const unsigned long long mask = __ballot(spawn);
@@ -453,6 +458,7 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     a.n_slots = (unsigned)tiles * 64u;
     a.records = ws.records;
     a.hit_t = (float *)d_hit_t;
+    a.normal = fp.d_normal;
     a.counters = ws.counters;
     a.stack_cap = fp.stack_depth;
 

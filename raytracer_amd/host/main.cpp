@@ -35,7 +35,7 @@ struct Config {
 } cfg;
 
 color *image = nullptr;                                      // main.cpp:16
-std::vector<float> image_rgb32;
+std::vector<float> image_rgb32, image_t, image_normal;
 std::vector<int32_t> image_ids;
 rt_ctx *ctx = nullptr;
 int exit_code = 0;
@@ -118,10 +118,15 @@ bool LoadModel(const char *model)
 // One pass of the pixel loop (main.cpp:262-277) on the GPU into `image`.
 bool render_once(bool report)
 {
-    if (!check(rt_render_frame(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, (uint8_t *)image,
-                               image_ids.empty() ? nullptr : image_ids.data(),
-                               image_rgb32.empty() ? nullptr : image_rgb32.data()),
-               "rt_render_frame"))
+    if (!image_t.empty()) {                        // EXR wanted: colour plus the t and normal planes
+        rt_frame_planes planes = { (uint8_t *)image, image_ids.data(), image_rgb32.data(), image_t.data(), image_normal.data() };
+        if (!check(rt_render_frame_planes(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, &planes),
+                   "rt_render_frame_planes"))
+            return false;
+    } else if (!check(rt_render_frame(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, (uint8_t *)image,
+                                      image_ids.empty() ? nullptr : image_ids.data(),
+                                      image_rgb32.empty() ? nullptr : image_rgb32.data()),
+                      "rt_render_frame"))
         return false;
     rt_stats st;
     if (!check(rt_get_stats(ctx, &st), "rt_get_stats")) return false;
@@ -170,13 +175,14 @@ void setup()
     image = new color[n];                                                       // main.cpp:259
     if (!cfg.pfm.empty() || !cfg.exr.empty()) image_rgb32.resize(3 * n);
     if (!cfg.ids.empty() || !cfg.exr.empty()) image_ids.resize(n);
+    if (!cfg.exr.empty()) { image_t.resize(n); image_normal.resize(3 * n); }
 
     printf("Rendering...\n");                                                   // main.cpp:261
     if (!render_once(true)) return;
 
     texturerenderer_set_output(cfg.out.empty() ? nullptr : cfg.out.c_str(), cfg.raw_order);
     if (!cfg.pfm.empty()) texturerenderer_set_float_output(cfg.pfm.c_str(), image_rgb32.data());
-    if (!cfg.exr.empty()) texturerenderer_set_exr_output(cfg.exr.c_str(), image_rgb32.data(), image_ids.data());
+    if (!cfg.exr.empty()) texturerenderer_set_exr_output(cfg.exr.c_str(), image_rgb32.data(), image_ids.data(), image_t.data(), image_normal.data());
     texturerenderer_displaytexture(image, cfg.imageWidth, cfg.imageHeight);    // main.cpp:281
     if (!cfg.ids.empty()) {
         if (FILE *f = fopen(cfg.ids.c_str(), "wb")) {

@@ -9,7 +9,7 @@
 
 namespace {
 std::string g_ppm, g_pfm, g_exr;
-const float *g_exr_rgb = nullptr;
+const float *g_exr_rgb = nullptr, *g_exr_t = nullptr, *g_exr_n = nullptr;
 const int *g_exr_ids = nullptr;
 bool g_raw = false;
 const color *g_pixels = nullptr;
@@ -32,11 +32,13 @@ void texturerenderer_set_float_output(const char *pfm_path, const float *rgb32)
     g_rgb32 = rgb32;
 }
 
-void texturerenderer_set_exr_output(const char *exr_path, const float *rgb32, const int *ids)
+void texturerenderer_set_exr_output(const char *exr_path, const float *rgb32, const int *ids, const float *hit_t, const float *normal)
 {
     g_exr = exr_path ? exr_path : "";
     g_exr_rgb = rgb32;
     g_exr_ids = ids;
+    g_exr_t = hit_t;
+    g_exr_n = normal;
 }
 
 namespace {
@@ -50,18 +52,29 @@ void attr(std::vector<unsigned char> &b, const char *name, const char *type, con
     put_str(b, name); put_str(b, type); put_i32(b, n); put(b, val, (size_t)n);
 }
 
-bool write_exr(const char *path, int w, int h, const float *rgb32, const int *ids)
+bool write_exr(const char *path, int w, int h, const float *rgb32, const int *ids, const float *hit_t, const float *normal)
 {
+    // channels in alphabetical order (upper case sorts first): B G [N.x N.y N.z] R [Z] [id]
+    struct Chan { const char *name; int type; const float *src; int stride, comp; const int *isrc; };
+    std::vector<Chan> chans;
+    chans.push_back({ "B", 2, rgb32, 3, 2, nullptr });
+    chans.push_back({ "G", 2, rgb32, 3, 1, nullptr });
+    if (normal) {
+        chans.push_back({ "N.x", 2, normal, 3, 0, nullptr });
+        chans.push_back({ "N.y", 2, normal, 3, 1, nullptr });
+        chans.push_back({ "N.z", 2, normal, 3, 2, nullptr });
+    }
+    chans.push_back({ "R", 2, rgb32, 3, 0, nullptr });
+    if (hit_t) chans.push_back({ "Z", 2, hit_t, 1, 0, nullptr });
+    if (ids) chans.push_back({ "id", 0, nullptr, 1, 0, ids });
+
     std::vector<unsigned char> hd;
     const unsigned char magic[8] = { 0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0 };
     put(hd, magic, 8);
-    // channels, alphabetical: B G R then id (upper case sorts first)
     std::vector<unsigned char> ch;
-    const char *names[4] = { "B", "G", "R", "id" };
-    const int n_ch = ids ? 4 : 3;
-    for (int c = 0; c < n_ch; c++) {
-        put_str(ch, names[c]);
-        put_i32(ch, c < 3 ? 2 : 0);                 // FLOAT / UINT
+    for (const Chan &c : chans) {
+        put_str(ch, c.name);
+        put_i32(ch, c.type);                        // 2 FLOAT, 0 UINT
         const unsigned char lin[4] = { 0, 0, 0, 0 };
         put(ch, lin, 4);
         put_i32(ch, 1); put_i32(ch, 1);             // sampling
@@ -82,24 +95,24 @@ bool write_exr(const char *path, int w, int h, const float *rgb32, const int *id
 
     FILE *f = fopen(path, "wb");
     if (!f) return false;
-    const size_t line_bytes = (size_t)w * 4 * (size_t)n_ch;
+    const size_t line_bytes = (size_t)w * 4 * chans.size();
     fwrite(hd.data(), 1, hd.size(), f);
     uint64_t off = hd.size() + 8ull * (uint64_t)h;
     for (int y = 0; y < h; y++, off += 8 + line_bytes) fwrite(&off, 8, 1, f);
     std::vector<float> row((size_t)w);
     std::vector<uint32_t> irow((size_t)w);
     for (int y = 0; y < h; y++) {
-        const int src = h - 1 - y;                  // buffer row 0 is the bottom of the picture
+        const size_t src = (size_t)(h - 1 - y) * (size_t)w;     // buffer row 0 is the bottom of the picture
         const int32_t hdr[2] = { y, (int32_t)line_bytes };
         fwrite(hdr, 4, 2, f);
-        for (int c = 0; c < 3; c++) {               // B, G, R
-            const int comp = 2 - c;
-            for (int x = 0; x < w; x++) row[(size_t)x] = rgb32[3 * ((size_t)src * w + x) + comp];
-            fwrite(row.data(), 4, (size_t)w, f);
-        }
-        if (ids) {
-            for (int x = 0; x < w; x++) irow[(size_t)x] = (uint32_t)(ids[(size_t)src * w + x] + 1);
-            fwrite(irow.data(), 4, (size_t)w, f);
+        for (const Chan &c : chans) {
+            if (c.type == 2) {
+                for (int x = 0; x < w; x++) row[(size_t)x] = c.src[(size_t)c.stride * (src + (size_t)x) + (size_t)c.comp];
+                fwrite(row.data(), 4, (size_t)w, f);
+            } else {
+                for (int x = 0; x < w; x++) irow[(size_t)x] = (uint32_t)(c.isrc[src + (size_t)x] + 1);
+                fwrite(irow.data(), 4, (size_t)w, f);
+            }
         }
     }
     fclose(f);
@@ -141,6 +154,6 @@ void texturerenderer_draw()
         }
     }
     if (!g_exr.empty() && g_exr_rgb) {
-        if (!write_exr(g_exr.c_str(), g_w, g_h, g_exr_rgb, g_exr_ids)) fprintf(stderr, "cannot write %s\n", g_exr.c_str());
+        if (!write_exr(g_exr.c_str(), g_w, g_h, g_exr_rgb, g_exr_ids, g_exr_t, g_exr_n)) fprintf(stderr, "cannot write %s\n", g_exr.c_str());
     }
 }

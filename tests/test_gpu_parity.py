@@ -268,6 +268,40 @@ def test_graph_replay_of_an_unchanged_frame_and_recapture_after_a_change():
     assert not np.array_equal(results[1][0][0], results[1][1][0])        # the camera move is visible
 
 
+def test_frame_planes_t_and_normal_of_the_primary_hit():
+    """rt_render_frame_planes on a linear-scan scene and on an LBVH scene: colour and ids as rt_render_frame,
+    t bit-equal to the oracle's, normals = the Triangle constructor's N (main.cpp:104-107) / the plane's n."""
+    for spec, W, H in ((cube_spec(mirror=False, mesh_reflect=0.5), 200, 150), (atrium_spec(detail=0.02, mirror=False), 160, 120)):
+        cam = rt.camera_for_width(W)
+        with rt.Context(0) as ctx:
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            ref = ctx.render_frame(W, H, max_depth=2)
+            g = ctx.render_frame_planes(W, H, max_depth=2)
+        for k in ("rgb8", "hit_id", "rgb32"):
+            assert np.array_equal(g[k].view(np.uint8), ref[k].view(np.uint8)), k
+        r = to_oracle(spec).render(W, H, max_depth=2, cam=ocam(cam), threads=8)
+        hit = g["hit_id"] >= 0
+        assert np.array_equal(g["hit_t"][hit].view(np.uint32), r["hit_t"][hit].view(np.uint32))
+        assert (g["normal"][~hit] == 0).all()
+        n_an = len(spec.analytic)
+        tri = g["hit_id"] >= n_an
+        assert tri.sum() > 500
+        v = spec.verts[spec.indices.reshape(-1, 3)]                       # (T, 3, 3)
+        e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+        n = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+        n /= np.linalg.norm(n, axis=1, keepdims=True)
+        want = n[g["hit_id"][tri] - n_an]
+        assert np.abs(g["normal"][tri] - want).max() < 2e-6
+        for i, a in enumerate(spec.analytic):
+            if a["kind"] == "plane":
+                m = g["hit_id"] == i
+                if m.any():
+                    assert np.array_equal(g["normal"][m], np.broadcast_to(np.asarray(a["p"], np.float32), (m.sum(), 3)))
+        ln = np.linalg.norm(g["normal"][hit].astype(np.float64), axis=1)
+        assert np.abs(ln - 1.0).max() < 1e-5
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
@@ -440,6 +474,7 @@ def test_host_relaxed_obj_with_mtl_materials_and_exr_output():
                         "--out", ppm, "--raw-order", "--exr", exr], check=True, capture_output=True, timeout=120)
         img, _ = _read_ppm(ppm)
         ex = _read_exr(exr)
+        assert sorted(ex) == ["B", "G", "N.x", "N.y", "N.z", "R", "Z", "id"]
     idx = np.array([[a, b, c, a, c, d] for a, b, c, d in q], np.int32).reshape(-1)
     tri_mat = np.repeat([0, 0, 1, 1, 2, 2], 2).astype(np.int32)
     spec = SceneSpec(stock_analytic(mirror=False), v, idx, mats=mats, tri_material=tri_mat)
@@ -448,6 +483,10 @@ def test_host_relaxed_obj_with_mtl_materials_and_exr_output():
     hid = ex["id"][::-1].astype(np.int64) - 1
     assert_parity(compare(dict(rgb8=img, hit_id=hid.astype(np.int32), rgb32=np.ascontiguousarray(f32)), r))
     assert (hid >= 4).sum() > 1000                                       # the cube is in view
+    seen = hid >= 0
+    assert np.array_equal(ex["Z"][::-1][seen].view(np.uint32), r["hit_t"][seen].view(np.uint32))
+    nrm = np.stack([ex["N.x"], ex["N.y"], ex["N.z"]], -1)[::-1]
+    assert np.abs(np.linalg.norm(nrm[seen], axis=1) - 1.0).max() < 1e-5 and (nrm[~seen] == 0).all()
 
 
 @pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
