@@ -33,9 +33,10 @@ __device__ __forceinline__ V2 plane_pair(unsigned int w, unsigned int sel_n, uns
 // is written through a reference stays in memory instead of registers.)
 __device__ __forceinline__ void slab_ray(const QuantGrid &g, F3 o, F3 d, F3 &inv_out, F3 &oi_out, uint3 &sel_n, uint3 &sel_f)
 {
-    // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf
-    F3 inv = mk(fminf(fmaxf(1.0f / d.x, -INV_MAX), INV_MAX), fminf(fmaxf(1.0f / d.y, -INV_MAX), INV_MAX),
-                fminf(fmaxf(1.0f / d.z, -INV_MAX), INV_MAX));
+    // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf.
+    // The hardware reciprocal (1 ulp) is enough here: these values only place the ray against padded boxes.
+    F3 inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -INV_MAX), INV_MAX), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -INV_MAX), INV_MAX),
+                fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -INV_MAX), INV_MAX));
     sel_n = make_uint3(inv.x < 0.0f ? SEL_HI : SEL_LO, inv.y < 0.0f ? SEL_HI : SEL_LO, inv.z < 0.0f ? SEL_HI : SEL_LO);
     sel_f = make_uint3(inv.x < 0.0f ? SEL_LO : SEL_HI, inv.y < 0.0f ? SEL_LO : SEL_HI, inv.z < 0.0f ? SEL_LO : SEL_HI);
     // lattice plane q (read as f = 1 + q/32768) maps to t = f*(32768*step*inv) + ((base - o)*inv - 32768*step*inv)

@@ -237,15 +237,7 @@ void k_trace(TraceArgs A)
                 if (live) {
                     best_t = FLT_MAX; best_id = -1;
                     if (!unit_any) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
-                    // 1/d clamped to a finite value: a zero component must not turn lo*inv - o*inv into inf - inf
-                    inv = mk(fminf(fmaxf(1.0f / d.x, -INV_MAX), INV_MAX), fminf(fmaxf(1.0f / d.y, -INV_MAX), INV_MAX),
-                             fminf(fmaxf(1.0f / d.z, -INV_MAX), INV_MAX));
-                    sel_n = make_uint3(inv.x < 0.0f ? SEL_HI : SEL_LO, inv.y < 0.0f ? SEL_HI : SEL_LO, inv.z < 0.0f ? SEL_HI : SEL_LO);
-                    sel_f = make_uint3(inv.x < 0.0f ? SEL_LO : SEL_HI, inv.y < 0.0f ? SEL_LO : SEL_HI, inv.z < 0.0f ? SEL_LO : SEL_HI);
-                    // lattice plane q (read as f = 1 + q/32768) maps to t = f*(32768*step*inv) + ((base - o)*inv - 32768*step*inv)
-                    oi = mk((sc.grid.base[0] - o.x) * inv.x, (sc.grid.base[1] - o.y) * inv.y, (sc.grid.base[2] - o.z) * inv.z);
-                    inv = mk(sc.grid.step[0] * 32768.0f * inv.x, sc.grid.step[1] * 32768.0f * inv.y, sc.grid.step[2] * 32768.0f * inv.z);
-                    oi = mk(oi.x - inv.x, oi.y - inv.y, oi.z - inv.z);
+                    slab_ray(sc.grid, o, d, inv, oi, sel_n, sel_f);
                     stack[0] = NODE_SENTINEL;
                     sp = 1;
                     tri_left = 0;
