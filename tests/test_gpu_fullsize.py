@@ -81,3 +81,42 @@ def test_soup_4m_triangles():
     sub = {k: a[k][::lat, ::lat] for k in ("rgb8", "rgb32", "hit_id")}
     rsub = {k: r[k][::lat, ::lat] for k in ("rgb8", "rgb32", "hit_id")}
     assert_parity(compare(sub, rsub))
+
+
+def test_sponza_4k_in_eight_band_parts(sponza):
+    """BASELINE's tile-partitioned configuration on one GPU: the 3840x2160 frame rendered as the eight
+    16-row band sets the eight ranks would take, reassembled on the device, equals the frame rendered
+    whole; a pixel lattice of it equals the CPU oracle; the parts cast exactly the frame's rays."""
+    import torch
+    wl0, ctx = sponza
+    wl = workloads.sponza(W=3840, H=2160)
+    W, H, D, parts, band = wl.W, wl.H, wl.max_depth, 8, 16
+    wl.load(ctx)                                    # same scene, the 4K camera
+    try:
+        whole = ctx.render_frame(W, H, max_depth=D, want=("rgb8", "hit_id"))
+        whole_rays = rays(ctx.stats())
+        cap = rt.rows_per_part(H, band, parts)
+        g8 = torch.zeros((parts, cap, W, 3), dtype=torch.uint8, device="cuda")
+        gid = torch.zeros((parts, cap, W), dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        total = [0, 0, 0]
+        for p in range(parts):
+            ctx.render_rows_device(W, H, rt.band_rowset(H, band, p, parts), D, g8[p].data_ptr(), gid[p].data_ptr(), None, None, stream)
+            torch.cuda.synchronize()
+            total = [a + b for a, b in zip(total, rays(ctx.stats()))]
+        out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        outid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        ctx.deinterleave_bands(g8.data_ptr(), out8.data_ptr(), W, H, band, parts, cap, 3, stream)
+        ctx.deinterleave_bands(gid.data_ptr(), outid.data_ptr(), W, H, band, parts, cap, 4, stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out8.cpu().numpy(), whole["rgb8"])
+        assert np.array_equal(outid.cpu().numpy(), whole["hit_id"])
+        assert tuple(total) == whole_rays
+        sc = O.scene_from_workload(wl, bvh=True)
+        lat = 6
+        r = sc.render(W, H, max_depth=D, cam=O.camera_from(wl.camera), use_bvh=True, threads=16, x_step=lat, y_step=lat)
+        assert np.array_equal(whole["hit_id"][::lat, ::lat], r["hit_id"][::lat, ::lat])
+        d = np.abs(whole["rgb8"][::lat, ::lat].astype(int) - r["rgb8"][::lat, ::lat].astype(int)).max(-1)
+        assert (d > 1).sum() == 0 and (d == 0).mean() >= 0.999
+    finally:
+        wl0.load(ctx)                               # leave the module's scene as the other tests expect it
