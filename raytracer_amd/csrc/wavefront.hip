@@ -1,17 +1,22 @@
-// wavefront.hip — the LBVH trace pipeline: traversal separated from shading.
+// wavefront.hip — the LBVH trace pipeline: traversal separated from ray generation and shading.
 //
 // The fused kernel in trace.hip keeps a whole ray's life in one thread; on LBVH scenes
 // its wave64 lanes spend most of their time masked off (rays end at different times,
-// node and leaf work serialise).  Here each bounce level of the reference's recursion
-// (Raytracer/main.cpp:144-217) is four wave-uniform stages over flat queues:
+// node and leaf work serialise).  Here the reference's recursion (Raytracer/main.cpp:144-217)
+// is run level by level over flat ray queues:
 //
-//   k_trace<closest>   nearest primitive per ray (main.cpp:147-156)        -> hits[slot]
-//   k_shadow_gen       per light: L, shadow-ray origin, analytic occluders
-//                      (main.cpp:178-188); survivors go to a per-light queue
-//   k_trace<any-hit>   any triangle accepting the shadow ray at any distance -> occ bits
-//   k_shade            local colour in the reference's accumulation order
-//                      (main.cpp:166-205), 16-byte record, reflection ray to the next
-//                      level's queue (main.cpp:208-211)
+//   k_trace<nearest, camera rays>                 nearest primitive per ray (main.cpp:147-156)
+//   for every level k:
+//     k_shadow_gen   hit point; the level-k+1 reflection ray (main.cpp:208-211) into the next
+//                    queue; per light: L, shadow-ray origin, analytic occluders
+//                    (main.cpp:178-188), survivors into one queue segment per light
+//     k_trace<mixed> ONE launch for the shadow rays of level k (any triangle at any distance
+//                    -> occlusion bit) and the nearest hits of level k+1: neither needs the other
+//   k_shade_all      (persistent.hip) per pixel: every level's local colour in the reference's
+//                    accumulation order (main.cpp:166-205), the fold, clamp and quantise
+//
+// Hits and occlusion bits live in planes indexed [level][pixel], so nothing has to be shaded
+// between the traversal launches.
 //
 // Queues are REGIONED: slot space is cut into regions of 256 slots; the block that
 // processes input region r writes its surviving rays densely at the start of output
@@ -22,10 +27,10 @@
 // k_trace is the hot kernel.  Waves are persistent and every LANE owns a ray: a lane
 // whose ray has finished goes idle and, once enough lanes of the wave are idle, they are
 // refilled from the wave's local range of rays; the wave claims a new 64-ray unit (one
-// atomic on a cursor sharded 8 ways, with stealing) only when that range is empty.
-// Lanes are either at an inner node or inside a leaf; each iteration the wave runs the
-// one step that more of its lanes are waiting for (ballot + popcount vote), so only one
-// body executes per iteration and at least half of the busy lanes advance.
+// atomic on a cursor sharded 64 ways, each on its own cache line, with stealing) only when
+// that range is empty.  Lanes are either at an inner node or at a leaf; each iteration the
+// wave runs the one step that more of its lanes are waiting for (ballot + popcount vote).
+// Inner nodes are 4-wide (BvhNode4): one dependent 64-byte fetch per two binary levels.
 // The per-lane traversal stack lives in LDS (16 entries, column-per-lane: conflict-free)
 // and overflows to a global column for the rare deeper path.
 #include "rt_traverse.h"
@@ -43,17 +48,8 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 16
 #endif
-#ifndef WF_LEAF_LOOP
-#define WF_LEAF_LOOP 1
-#endif
-#ifndef WF_ANYHIT_NEAR
-#define WF_ANYHIT_NEAR 0
-#endif
 #ifndef WF_UNIT
 #define WF_UNIT 64
-#endif
-#ifndef WF_LEAF_MIN
-#define WF_LEAF_MIN 0
 #endif
 #ifndef WF_WIDE
 #define WF_WIDE 1          // traverse the 4-wide nodes (one dependent fetch per two binary levels)
@@ -75,9 +71,6 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #endif
 #ifndef WF_WAVES_EU_MIXED
 #define WF_WAVES_EU_MIXED 7   // the mixed-kind kernel carries more state: 7 waves avoid spills in its loop
-#endif
-#ifndef WF_VOTE
-#define WF_VOTE 1
 #endif
 constexpr int REFILL_MIN = WF_REFILL_MIN; // refill once this many lanes of a wave are idle
 constexpr int REGION = BLOCK;             // slots per queue region = one producer block iteration
@@ -254,9 +247,9 @@ void k_trace(TraceArgs A)
             continue;
         }
 
-        const bool do_node = WF_VOTE ? (WF_LEAF_MIN ? (__popcll(m_leaf) < WF_LEAF_MIN && m_node != 0ull) : (__popcll(m_node) >= __popcll(m_leaf)))
-                                     : (m_node != 0ull);
-        const bool do_leaf = WF_VOTE ? !do_node : (m_leaf != 0ull);
+        // the step more lanes are waiting for
+        const bool do_node = __popcll(m_node) >= __popcll(m_leaf);
+        const bool do_leaf = !do_node;
         if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); }
         if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
         if (do_node) {
@@ -346,7 +339,7 @@ void k_trace(TraceArgs A)
                 node_test(qa, qb, inv, oi, sel_n, sel_f, tmax, n0, n1, h0, h1);
                 if (COUNT) tl.box += 2;
                 if (h0 && h1) {
-                    const bool swap = (WF_ANYHIT_NEAR || !ANYHIT) && n1 < n0;
+                    const bool swap = !ANYHIT && n1 < n0;
                     push(swap ? ch.x : ch.y);
                     node = swap ? ch.y : ch.x;
                 } else if (h0) {
@@ -360,16 +353,14 @@ void k_trace(TraceArgs A)
             }
         }
         if (do_leaf) {
-            // ---- leaf step: one triangle through the reference's Moller-Trumbore test
+            // ---- leaf step: every triangle of the leaf through the reference's Moller-Trumbore test
             if (node < 0) {
                 if (tri_left == 0) {
                     const int leaf = ~node;
                     tri_i = leaf >> 3;
                     tri_left = (leaf & 7) + 1;
                 }
-#if WF_LEAF_LOOP
                 for (;;) {
-#endif
                 const float4 v1 = sc.bvh_tri[3 * (size_t)tri_i];
                 const F3 e1 = f3(sc.bvh_tri[3 * (size_t)tri_i + 1]), e2 = f3(sc.bvh_tri[3 * (size_t)tri_i + 2]);
                 float t;
@@ -387,10 +378,8 @@ void k_trace(TraceArgs A)
                     const int id = sc.n_analytic + __float_as_int(v1.w);
                     if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
                 }
-#if WF_LEAF_LOOP
                 if (node == NODE_SENTINEL || tri_left == 0) break;
                 }
-#endif
                 if (node != NODE_SENTINEL && tri_left == 0) pop();
             }
         }
