@@ -302,6 +302,34 @@ def test_frame_planes_t_and_normal_of_the_primary_hit():
         assert np.abs(ln - 1.0).max() < 1e-5
 
 
+@pytest.mark.parametrize("n_tris", [2, 3, 4, 5, 7, 9, 17])
+def test_tiny_meshes_through_every_hierarchy_shape(n_tris):
+    """Two to seventeen triangles forced through the hierarchy pipelines (wide nodes with one to four
+    children, a root whose children are leaves, every leaf size, both builders, all three pipelines):
+    each equals the linear scan bit for bit, and the linear scan equals the oracle."""
+    spec = soup_spec(n_tris, seed=100 + n_tris)
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 160, 120, 3
+    base = render(spec, W, H, D, cam, rt.ACCEL_LINEAR)
+    assert_parity(compare(base, to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam))))
+    for builder in (rt.BUILDER_LBVH, rt.BUILDER_PLOC):
+        for leaf_max in (1, 2, 8):
+            for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_PERSISTENT):
+                with rt.Context(0) as ctx:
+                    ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+                    ctx.set_option(rt.OPT_BUILDER, builder)
+                    ctx.set_option(rt.OPT_LEAF_MAX, leaf_max)
+                    ctx.set_option(rt.OPT_PIPELINE, pipeline)
+                    to_product(ctx, spec)
+                    ctx.set_camera(cam)
+                    g = ctx.render_frame(W, H, max_depth=D)
+                    st = ctx.stats()
+                assert st["accel"] == 1
+                for k in ("rgb8", "hit_id", "rgb32"):
+                    assert np.array_equal(g[k].view(np.uint8), base[k].view(np.uint8)), (k, builder, leaf_max, pipeline)
+                assert rays(st) == rays(base["stats"])
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
