@@ -712,6 +712,10 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
         if (err) *err = "triangle count beyond the leaf encoding (2^28)";
         return RT_E_LIMIT;
     }
+    if (((long long)n + WIDE_TOP_NODES) * (long long)sizeof(BvhNode4) >= (1ll << 32)) {
+        if (err) *err = "triangle count beyond the 32-bit byte offsets of the wide node array (2^26)";
+        return RT_E_LIMIT;
+    }
     const int n_tiles = blocks_for(n, SORT_TILE);
     DevBuf<unsigned int> bounds, vals[2], hist;
     DevBuf<unsigned long long> keys[2];

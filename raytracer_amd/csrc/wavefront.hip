@@ -266,8 +266,10 @@ void k_trace(TraceArgs A)
                 } else
 #endif
                 {
-                    const BvhNode4 *np = sc.wnodes + node;
-                    qa = np->a; qb = np->b; qc = np->c; qd = np->d;
+                    // 32-bit byte offset from the uniform base: one shift instead of 64-bit address arithmetic
+                    // (the builder keeps the wide node array below 4 GiB)
+                    const uint4 *np = (const uint4 *)((const char *)sc.wnodes + (unsigned)node * 64u);
+                    qa = np[0]; qb = np[1]; qc = np[2]; qd = np[3];
                 }
                 float dk[4];
                 int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
@@ -361,8 +363,10 @@ void k_trace(TraceArgs A)
                     tri_left = (leaf & 7) + 1;
                 }
                 for (;;) {
-                const float4 v1 = sc.bvh_tri[3 * (size_t)tri_i];
-                const F3 e1 = f3(sc.bvh_tri[3 * (size_t)tri_i + 1]), e2 = f3(sc.bvh_tri[3 * (size_t)tri_i + 2]);
+                // 32-bit byte offset (48 bytes per triangle; the builder's triangle limit keeps it below 4 GiB)
+                const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)tri_i * 48u);
+                const float4 v1 = tp[0];
+                const F3 e1 = f3(tp[1]), e2 = f3(tp[2]);
                 float t;
                 const bool h = tri_raycast(f3(v1), e1, e2, o, d, t);
                 if (COUNT) tl.tri += 1;
