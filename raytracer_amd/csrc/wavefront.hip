@@ -248,7 +248,7 @@ void k_trace(TraceArgs A)
         }
 
         // the step more lanes are waiting for
-        const bool do_node = __popcll(m_node) >= __popcll(m_leaf);
+        const bool do_node = (int)__popcll(m_node) >= (int)__popcll(m_leaf);
         const bool do_leaf = !do_node;
         if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); }
         if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
