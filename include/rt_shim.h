@@ -86,8 +86,9 @@ typedef struct {
     uint64_t rays_primary, rays_shadow, rays_reflect;
     uint64_t box_tests, tri_tests, analytic_tests;   /* only with RT_OPT_COUNT_TESTS = 1 */
     float ms_frame;        /* device time of the last frame, first kernel to last kernel */
-    float ms_trace;        /* sum of the bounce (traversal + shading) kernels */
-    float ms_resolve;      /* recombination + quantise kernel */
+    float ms_trace;        /* everything before the last kernel: traversal and ray generation (staged pipeline), or the
+                              per-level bounce kernels (fused) */
+    float ms_resolve;      /* the last kernel: shading of every level + fold + quantise (staged), or fold + quantise (fused) */
     int32_t n_launches;    /* kernels launched for the frame */
     int32_t n_analytic, n_triangles;
     int32_t bvh_nodes, bvh_depth, bvh_leaf_max;
