@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X trace path.
 
-Metric (BASELINE.json): Mrays/s (primary + shadow + reflect, counted as the reference would
+Metric: Mrays/s (primary + shadow + reflect, counted as the reference would
 cast them) on the Sponza-class workload at 1920x1080 with hard shadows and 4 reflection
 bounces, on N GPUs of one node (frame tile-partitioned, scene replicated, RGB8 slices
-gathered with RCCL).  One "step" = one full frame: every bounce level's trace kernel, the
-resolve/quantise kernel and, for N > 1, the gather + de-interleave.  The scene (triangles,
+gathered with RCCL).  One "step" = one full frame: every traversal, ray-generation
+and shading launch of all bounce levels and, for N > 1, the gather + de-interleave.  The scene (triangles,
 LBVH) is resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W

@@ -84,7 +84,7 @@ def test_soup_4m_triangles():
 
 
 def test_sponza_4k_in_eight_band_parts(sponza):
-    """BASELINE's tile-partitioned configuration on one GPU: the 3840x2160 frame rendered as the eight
+    """The tile-partitioned 4K configuration on one GPU: the 3840x2160 frame rendered as the eight
     16-row band sets the eight ranks would take, reassembled on the device, equals the frame rendered
     whole; a pixel lattice of it equals the CPU oracle; the parts cast exactly the frame's rays."""
     import torch

@@ -76,7 +76,7 @@ def test_golden_scenes(name, accel, leaf_max, flat, golden_scenes):
     assert g["stats"]["accel"] == (1 if (accel == rt.ACCEL_LBVH and spec.n_tris >= 2) else 0)
 
 
-# ------------------------------------------------------------------ against the oracle, BASELINE configs
+# ------------------------------------------------------------------ against the oracle, the benchmark configurations
 def test_config_cube_512_one_bounce():
     spec = cube_spec(mirror=False, mesh_reflect=0.5)
     cam = rt.camera_for_width(512)

@@ -27,7 +27,7 @@ def test_stock_frame_fixture_is_the_canonical_frame(golden_stock):
 def test_oracle_reproduces_stock_frame_byte_for_byte(golden_stock):
     r = to_oracle(stock_spec()).render(800, 600, max_depth=3)
     assert np.array_equal(r["rgb8"], golden_stock["rgb8"])
-    # ray counts of the reference on this frame (counter-instrumented copy)
+    # ray counts of the reference on this frame (from a counter-instrumented copy of it)
     assert (r["counts"]["primary"], r["counts"]["shadow"], r["counts"]["reflect"]) == (480000, 1112248, 236124)
 
 
