@@ -140,6 +140,15 @@ int rt_set_triangles(rt_ctx *ctx, const float *tri_verts, int n_tris, const rt_m
 int rt_set_triangle_materials(rt_ctx *ctx, const rt_material *mats, int n_mats,
                               const int32_t *tri_material, int n_tris);
 
+/* Moving geometry for the per-tick re-render (draw(dt), main.cpp:284-287, glwt.mm:68-82; the reference
+ * itself redraws one static frame): new positions for the triangles already loaded, same count and
+ * order.  Materials and the hierarchy's topology stay; the Triangle constructor (main.cpp:104-107) runs
+ * again and the hierarchy's boxes are refitted on the device (rt_stats.ms_build then reports the refit).
+ * rt_update_triangles pairs with rt_set_triangles (n_tris x 9 floats), rt_update_mesh_vertices with
+ * rt_set_mesh (n_verts x 3 floats under the indices kept from that call).  RT_E_STATE on a count mismatch. */
+int rt_update_triangles(rt_ctx *ctx, const float *tri_verts, int n_tris);
+int rt_update_mesh_vertices(rt_ctx *ctx, const float *verts, int n_verts);
+
 /* Replaces the literals of main.cpp:267-270.  NULL restores the reference camera. */
 int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 

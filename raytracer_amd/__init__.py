@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_option", "rt_set_analytic",
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
+    "rt_update_triangles", "rt_update_mesh_vertices",
 )
 
 
@@ -162,6 +163,8 @@ def load_library():
     L.rt_set_mesh.argtypes = [vp, vp, i32, vp, i32, C.POINTER(Material)]
     L.rt_set_triangles.argtypes = [vp, vp, i32, C.POINTER(Material)]
     L.rt_set_triangle_materials.argtypes = [vp, C.POINTER(Material), i32, vp, i32]
+    L.rt_update_triangles.argtypes = [vp, vp, i32]
+    L.rt_update_mesh_vertices.argtypes = [vp, vp, i32]
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rt_render_frame.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.rt_render_frame_planes.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(FramePlanes)]
@@ -229,6 +232,16 @@ class Context:
         tm = np.ascontiguousarray(tri_material, dtype=np.int32).reshape(-1)
         arr = (Material * len(mats))(*mats)
         self._check(self.L.rt_set_triangle_materials(self._h, arr, len(mats), tm.ctypes.data, tm.shape[0]))
+
+    def update_triangles(self, tri_verts):
+        """rt_update_triangles: moved vertices for the loaded triangles (same count and order)."""
+        v = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+        self._check(self.L.rt_update_triangles(self._h, v.ctypes.data, v.shape[0]))
+
+    def update_mesh_vertices(self, verts):
+        """rt_update_mesh_vertices: moved vertices under the indices given to set_mesh."""
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        self._check(self.L.rt_update_mesh_vertices(self._h, v.ctypes.data, v.shape[0]))
 
     def set_camera(self, cam=None):
         self._check(self.L.rt_set_camera(self._h, C.byref(cam) if cam is not None else None))

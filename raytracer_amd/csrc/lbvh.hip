@@ -21,6 +21,8 @@
 
 #include <float.h>
 
+#include <new>
+
 namespace {
 
 constexpr int SORT_TILE = 1024;   // keys per wave-sized block in the radix sort
@@ -50,7 +52,8 @@ __device__ inline void tri_ctor(float ax, float ay, float az, float bx, float by
     tri_mt[3 * (size_t)i + 0] = make_float4(ax, ay, az, 0.f);
     tri_mt[3 * (size_t)i + 1] = make_float4(e1x, e1y, e1z, 0.f);
     tri_mt[3 * (size_t)i + 2] = make_float4(e2x, e2y, e2z, 0.f);
-    tri_n[i] = make_float4(nx / len, ny / len, nz / len, __int_as_float(mat_index));
+    const float w = mat_index < 0 ? tri_n[i].w : __int_as_float(mat_index);   // < 0: keep the stored material index
+    tri_n[i] = make_float4(nx / len, ny / len, nz / len, w);
 }
 
 __global__ void k_tri_setup_flat(const float *__restrict__ v, int n, float4 *tri_mt, float4 *tri_n, int mat_index)
@@ -665,11 +668,31 @@ template <typename T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
+    T *release() { T *q = p; p = nullptr; return q; }
 };
 
 inline int blocks_for(int n, int bs) { return (n + bs - 1) / bs; }
 
 }  // namespace
+
+// What a refit needs from the build: the binary tree over the sorted triangles and the numbering of
+// the emitted nodes.  None of it depends on where the vertices are, only on which triangle sits where.
+struct LbvhTopology {
+    int n = 0, max_depth = 0;
+    bool ploc = false;
+    unsigned int *bounds = nullptr, *vals = nullptr;
+    int2 *children = nullptr, *range = nullptr;
+    int *parent = nullptr, *depth = nullptr, *scalars = nullptr, *leafpos = nullptr, *order = nullptr;
+    int *live = nullptr, *pre = nullptr, *pre4 = nullptr, *slot = nullptr;
+    float4 *box_lo = nullptr, *box_hi = nullptr;
+    QuantGrid *grid = nullptr;
+    ~LbvhTopology()
+    {
+        void *ptrs[] = { bounds, vals, children, range, parent, depth, scalars, leafpos, order, live, pre, pre4, slot, box_lo, box_hi, grid };
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+};
 
 int tri_setup_flat(const float *d_tri_verts, int n_tris, float4 *tri_mt, float4 *tri_n, int mat_index, hipStream_t stream)
 {
@@ -694,6 +717,7 @@ void lbvh_free(LbvhResult *r)
     if (r->qnodes) (void)hipFree(r->qnodes);
     if (r->wnodes) (void)hipFree(r->wnodes);
     if (r->bvh_tri) (void)hipFree(r->bvh_tri);
+    delete r->topo;
     *r = LbvhResult();
 }
 
@@ -873,6 +897,56 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     out->depth = live_depth;
     out->wide_depth = wide_depth;
     out->leaf_max = leaf_max;
+    out->ms_build = ms;
+    LbvhTopology *t = new (std::nothrow) LbvhTopology;
+    if (t) {
+        t->n = n; t->max_depth = max_depth; t->ploc = ploc;
+        t->bounds = bounds.release(); t->vals = vals[cur].release();
+        t->children = children.release(); t->range = range.release(); t->parent = parent.release();
+        t->depth = depth.release(); t->scalars = scalars.release();
+        t->leafpos = leafpos.release(); t->order = order.release();
+        t->live = live.release(); t->pre = pre.release(); t->pre4 = pre4.release(); t->slot = slot.release();
+        t->box_lo = box_lo.release(); t->box_hi = box_hi.release(); t->grid = grid.release();
+    }
+    out->topo = t;
+    return RT_OK;
+}
+
+// New vertex positions under the same tree: leaf boxes, bottom-up unions, then the node arrays and the
+// triangle copy are written again.  The lattice follows the new root box.  Which triangles share a leaf
+// does not change, so a large deformation costs traversal steps, never correctness.
+int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out, std::string *err)
+{
+    LbvhTopology *t = out->topo;
+    if (!t || !out->wnodes || t->n != n) {
+        if (err) *err = "lbvh_refit: no hierarchy over this many triangles";
+        return RT_E_STATE;
+    }
+    hipEvent_t ev0, ev1;
+    RT_HIP_CHECK(hipEventCreate(&ev0), err);
+    RT_HIP_CHECK(hipEventCreate(&ev1), err);
+    RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
+    const int B = 256, G = blocks_for(n, B), GI = blocks_for(n - 1, B);
+    const int *leafpos = t->ploc ? t->leafpos : (const int *)nullptr;
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, t->bounds);
+    hipLaunchKernelGGL(k_bounds, dim3(G), dim3(B), 0, stream, tri_mt, n, t->bounds);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, n, t->bounds, t->box_lo, t->box_hi);
+    for (int level = t->max_depth; level >= 0; level--)
+        hipLaunchKernelGGL(k_refit_level, dim3(GI), dim3(B), 0, stream, t->children, t->depth, n - 1, level, t->box_lo, t->box_hi);
+    hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->parent, t->depth, n, out->leaf_max,
+                       t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, out->qnodes, t->grid, t->scalars + 1);
+    hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->depth, t->live, n, out->leaf_max,
+                       t->box_lo, t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
+    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, t->ploc ? t->order : (const int *)nullptr, n,
+                       out->bvh_tri);
+    RT_HIP_CHECK(hipGetLastError(), err);
+    RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
+    RT_HIP_CHECK(hipMemcpyAsync(&out->grid, t->grid, sizeof(QuantGrid), hipMemcpyDeviceToHost, stream), err);
+    RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
     out->ms_build = ms;
     return RT_OK;
 }

@@ -101,7 +101,10 @@ struct FrameCounters {
 
 // ------------------------------------------------------------------ host-side state
 
+struct LbvhTopology;   // lbvh.hip: what the build keeps so that lbvh_refit can follow moving vertices
+
 struct LbvhResult {
+    LbvhTopology *topo = nullptr;
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
     BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
     BvhNode4 *wnodes = nullptr;    // [WIDE_TOP_NODES + max(n_tris-1,1)] (about a quarter used)
@@ -115,6 +118,8 @@ struct LbvhResult {
 int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, int builder, hipStream_t stream, LbvhResult *out,
                std::string *err);
 void lbvh_free(LbvhResult *r);
+// lbvh.hip: the same tree over moved vertices (same triangle count and order as the build).
+int lbvh_refit(const float4 *tri_mt, int n_tris, hipStream_t stream, LbvhResult *out, std::string *err);
 
 // lbvh.hip: Triangle constructor (main.cpp:104-107) on the device.
 int tri_setup_flat(const float *d_tri_verts, int n_tris, float4 *tri_mt, float4 *tri_n, int mat_index,

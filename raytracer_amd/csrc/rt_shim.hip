@@ -30,6 +30,8 @@ struct rt_ctx {
     int n_analytic = 0, n_lights = 0;
     float4 *d_tri_mt = nullptr, *d_tri_n = nullptr;
     int n_tris = 0;
+    int32_t *d_indices = nullptr;   // kept from rt_set_mesh for rt_update_mesh_vertices
+    int n_mesh_verts = 0;
     DevMaterial *d_mats = nullptr;
     int n_mats = 0;
     LbvhResult bvh;
@@ -95,8 +97,11 @@ void free_triangles(rt_ctx *c)
     if (c->d_tri_mt) (void)hipFree(c->d_tri_mt);
     if (c->d_tri_n) (void)hipFree(c->d_tri_n);
     if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_indices) (void)hipFree(c->d_indices);
     c->d_tri_mt = c->d_tri_n = nullptr;
     c->d_mats = nullptr;
+    c->d_indices = nullptr;
+    c->n_mesh_verts = 0;
     c->n_tris = 0;
     c->n_mats = 0;
     lbvh_free(&c->bvh);
@@ -567,9 +572,84 @@ int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indic
     if (rc == RT_OK && bad) rc = fail(RT_E_INVALID, "vertex index out of range");
     (void)hipStreamSynchronize(c->stream);
     if (d_v) (void)hipFree(d_v);
-    if (d_i) (void)hipFree(d_i);
     if (d_bad) (void)hipFree(d_bad);
-    if (rc != RT_OK) free_triangles(c);
+    if (rc != RT_OK) {
+        if (d_i) (void)hipFree(d_i);
+        free_triangles(c);
+    } else {
+        c->d_indices = d_i;
+        c->n_mesh_verts = n_verts;
+    }
+    return rc;
+}
+
+namespace {
+
+// After the Triangle constructor has run again over moved vertices: refit the hierarchy if one exists
+// (or build it if this frame's settings want one and none is there).
+int after_vertex_update(rt_ctx *c)
+{
+    c->state_version++;
+    c->frame_valid = false;
+    if (c->bvh.wnodes && c->bvh.leaf_max == c->opt_leaf_max && c->bvh.builder == c->opt_builder) {
+        std::string err;
+        int rc = lbvh_refit(c->d_tri_mt, c->n_tris, c->stream, &c->bvh, &err);
+        if (rc != RT_OK) return fail(rc, err);
+        return RT_OK;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(RT_E_DEVICE, "triangle set-up failed");
+    int accel = 0;
+    return ensure_accel(c, &accel);
+}
+
+}  // namespace
+
+int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (!tri_verts) return fail(RT_E_INVALID, "null vertex array");
+    if (c->n_tris == 0 || n_tris != c->n_tris) return fail(RT_E_STATE, "triangle count does not match the loaded triangles");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    float *d_v = nullptr;
+    if (hipMalloc((void **)&d_v, sizeof(float) * 9 * (size_t)n_tris) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
+    int rc = RT_OK;
+    if (hipMemcpyAsync(d_v, tri_verts, sizeof(float) * 9 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(RT_E_DEVICE, "upload triangle vertices");
+    if (rc == RT_OK && tri_setup_flat(d_v, n_tris, c->d_tri_mt, c->d_tri_n, -1, c->stream) != RT_OK)
+        rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
+    if (rc == RT_OK) rc = after_vertex_update(c);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_v);
+    return rc;
+}
+
+int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    if (!verts) return fail(RT_E_INVALID, "null vertex array");
+    if (!c->d_indices || c->n_tris == 0) return fail(RT_E_STATE, "no indexed mesh loaded (rt_set_mesh)");
+    if (n_verts != c->n_mesh_verts) return fail(RT_E_STATE, "vertex count does not match the loaded mesh");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    float *d_v = nullptr;
+    int *d_bad = nullptr;
+    if (hipMalloc((void **)&d_v, sizeof(float) * 3 * (size_t)n_verts) != hipSuccess ||
+        hipMalloc((void **)&d_bad, sizeof(int)) != hipSuccess) {
+        if (d_v) (void)hipFree(d_v);
+        return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
+    }
+    int rc = RT_OK;
+    if (hipMemcpyAsync(d_v, verts, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemsetAsync(d_bad, 0, sizeof(int), c->stream) != hipSuccess)
+        rc = fail(RT_E_DEVICE, "upload vertices");
+    // the indices were range-checked against this vertex count when the mesh was loaded
+    if (rc == RT_OK && tri_setup_indexed(d_v, n_verts, c->d_indices, c->n_tris, c->d_tri_mt, c->d_tri_n, -1, d_bad, c->stream) != RT_OK)
+        rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
+    if (rc == RT_OK) rc = after_vertex_update(c);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_v);
+    (void)hipFree(d_bad);
     return rc;
 }
 

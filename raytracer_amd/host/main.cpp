@@ -7,10 +7,11 @@
 //   raytracer [--out frame.ppm] [--raw-order] [--pfm frame.pfm] [--ids ids.bin]
 //             [--width W] [--height H] [--depth D] [--obj mesh.obj] [--mesh-reflect K]
 //             [--no-mirror] [--no-floor] [--device N] [--dump-obj mesh.obj]
-//             [--relaxed] [--exr frame.exr] [--frames N] [--dump-obj-relaxed mesh.obj]
+//             [--relaxed] [--exr frame.exr] [--frames N] [--wobble A] [--dump-obj-relaxed mesh.obj]
 //
 // --relaxed reads the OBJ with the tolerant parser and takes materials from its .mtl files;
-// --frames N re-renders from draw(dt) with the camera swinging sideways, N - 1 more times.
+// --frames N re-renders from draw(dt) with the camera swinging sideways, N - 1 more times;
+// --wobble A also sways the mesh vertices by up to A units per tick (the hierarchy is refitted).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@ struct Config {
     bool raw_order = false, mirror = true, floor = true, relaxed = false;
     int frames = 1;
     float mesh_reflect = 0.0f;                               // main.cpp:34: meshes do not reflect
+    float wobble = 0.0f;
     int device = 0;
 } cfg;
 
@@ -40,7 +42,8 @@ std::vector<int32_t> image_ids;
 rt_ctx *ctx = nullptr;
 int exit_code = 0;
 int frames_rendered = 0;
-double total_rays = 0.0, total_device_ms = 0.0, clock_s = 0.0;
+double total_rays = 0.0, total_device_ms = 0.0, total_refit_ms = 0.0, clock_s = 0.0;
+std::vector<float> rest_verts, moved_verts;                  // mesh vertices as loaded / as animated (--wobble)
 rt_camera base_cam;
 bool render_once(bool report);
 
@@ -92,6 +95,7 @@ bool LoadModel(const char *model)
         for (const ObjMaterial &om : m.materials)
             mats.push_back(material(om.reflect, om.diffuse, om.spec, om.color[0], om.color[1], om.color[2]));
         if (cfg.mesh_reflect > 0.0f) mats[0].reflect = cfg.mesh_reflect;      // faces without usemtl
+        if (!m.vertices.empty()) rest_verts.assign(&m.vertices[0].x, &m.vertices[0].x + 3 * m.vertices.size());
         if (!check(rt_set_mesh(ctx, m.vertices.empty() ? nullptr : &m.vertices[0].x, (int)m.vertices.size(), m.indices.data(),
                                (int)m.indices.size(), &mats[0]),
                    "rt_set_mesh"))
@@ -111,6 +115,7 @@ bool LoadModel(const char *model)
         return false;
     }
     rt_material m = material(cfg.mesh_reflect, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f);
+    if (!verts.empty()) rest_verts.assign(&verts[0].x, &verts[0].x + 3 * verts.size());
     return check(rt_set_mesh(ctx, verts.empty() ? nullptr : &verts[0].x, (int)verts.size(), inds.data(), (int)inds.size(), &m),
                  "rt_set_mesh");
 }
@@ -204,10 +209,28 @@ void draw(float dt)
         const float swing = 1.5f * sinf((float)clock_s * 2.0f);
         cam.origin[0] += swing;
         cam.off_x += swing;
-        if (check(rt_set_camera(ctx, &cam), "rt_set_camera")) render_once(false);
-        if (frames_rendered == cfg.frames && total_device_ms > 0.0)
+        bool ok = check(rt_set_camera(ctx, &cam), "rt_set_camera");
+        if (ok && cfg.wobble != 0.0f && !rest_verts.empty()) {
+            // a travelling wave through the mesh: same triangles, new positions, tree refitted on the device
+            moved_verts.resize(rest_verts.size());
+            for (size_t k = 0; k < rest_verts.size(); k += 3) {
+                const float x = rest_verts[k], y = rest_verts[k + 1], z = rest_verts[k + 2];
+                const float ph = (float)clock_s * 3.0f;
+                moved_verts[k] = x + cfg.wobble * sinf(ph + y * 0.7f);
+                moved_verts[k + 1] = y + cfg.wobble * 0.5f * sinf(ph * 1.3f + z * 0.5f);
+                moved_verts[k + 2] = z + cfg.wobble * cosf(ph + x * 0.6f);
+            }
+            ok = check(rt_update_mesh_vertices(ctx, moved_verts.data(), (int)(moved_verts.size() / 3)), "rt_update_mesh_vertices");
+            rt_stats st;
+            if (ok && rt_get_stats(ctx, &st) == RT_OK) total_refit_ms += st.ms_build;
+        }
+        if (ok) render_once(false);
+        if (frames_rendered == cfg.frames && total_device_ms > 0.0) {
             printf("%d frames, %.3f ms/frame (device), %.1f Mrays/s sustained\n", frames_rendered, total_device_ms / frames_rendered,
                    total_rays / (total_device_ms * 1e3));
+            if (cfg.wobble != 0.0f && !rest_verts.empty())
+                printf("refit %.3f ms/frame (device)\n", total_refit_ms / (frames_rendered - 1));
+        }
         texturerenderer_displaytexture(image, cfg.imageWidth, cfg.imageHeight);
         if (frames_rendered < cfg.frames) return;          // files are written once, with the last frame
     }
@@ -265,6 +288,7 @@ int main(int argc, char *argv[])
         else if (a == "--relaxed") cfg.relaxed = true;
         else if (a == "--exr") cfg.exr = val();
         else if (a == "--frames") cfg.frames = atoi(val());
+        else if (a == "--wobble") cfg.wobble = (float)atof(val());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     glwt_headless_frames = cfg.frames > 1 ? cfg.frames : 1;

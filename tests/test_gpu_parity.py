@@ -330,6 +330,87 @@ def test_tiny_meshes_through_every_hierarchy_shape(n_tris):
                 assert rays(st) == rays(base["stats"])
 
 
+# ------------------------------------------------------------------ moving geometry (refit)
+def _moved(verts, step):
+    """A deformation that changes the scene bounds: a swell along x and a shear in y, growing with step."""
+    v = verts.astype(np.float64).copy()
+    v[:, 0] *= 1.0 + 0.15 * step
+    v[:, 1] += 0.4 * step * np.sin(v[:, 2] * 1.7 + step)
+    v[:, 2] += 0.25 * step * np.cos(v[:, 0] * 0.9)
+    return v.astype(np.float32)
+
+
+@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC])
+@pytest.mark.parametrize("flat", [False, True])
+def test_refit_after_vertex_updates_equals_a_fresh_build_and_the_oracle(builder, flat):
+    """rt_update_mesh_vertices / rt_update_triangles keep the tree and refit its boxes: every frame
+    after an update equals, bit for bit, the frame of a context that was given the moved vertices from
+    the start, and that frame equals the oracle's.  Per-triangle materials survive the update."""
+    spec = soup_spec(n_tris=600, seed=21)
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 160, 120, 3
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+        ctx.set_option(rt.OPT_BUILDER, builder)
+        to_product(ctx, spec, flat=flat)
+        ctx.set_camera(cam)
+        ctx.render_frame(W, H, max_depth=D)
+        nodes0 = ctx.stats()["bvh_nodes"]
+        for step in (1, 2, 3):
+            v = _moved(spec.verts, step)
+            if flat:
+                ctx.update_triangles(scenes.flatten(v, spec.indices))
+            else:
+                ctx.update_mesh_vertices(v)
+            g = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            assert st["accel"] == 1 and st["bvh_nodes"] == nodes0
+            moved = SceneSpecCopy(spec, v)
+            fresh = render(moved, W, H, D, cam, rt.ACCEL_LBVH, leaf_max=2, flat=flat)
+            for k in ("rgb8", "hit_id", "rgb32"):
+                assert np.array_equal(g[k].view(np.uint8), fresh[k].view(np.uint8)), (k, step)
+            assert rays(st) == rays(fresh["stats"])
+            if step == 3:
+                r = to_oracle(moved).render(W, H, max_depth=D, cam=ocam(cam))
+                assert_parity(compare(g, r))
+                assert rays(st) == orays(r)
+
+
+def SceneSpecCopy(spec, verts):
+    from common import SceneSpec
+    return SceneSpec(spec.analytic, verts, spec.indices, spec.mesh_mat, spec.mats, spec.tri_material)
+
+
+def test_vertex_update_of_a_linear_scan_scene_and_count_mismatches():
+    """Below the hierarchy threshold the update only reruns the Triangle constructor; wrong counts and
+    an update without a mesh are refused with RT_E_STATE and leave the scene as it was."""
+    spec = soup_spec(n_tris=12, seed=5)
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 96, 64, 2
+    with rt.Context(0) as ctx:
+        ctx.set_analytic(rt.stock_scene())
+        with pytest.raises(rt.RtError) as e:
+            ctx.update_triangles(np.zeros((4, 9), np.float32))          # nothing loaded
+        assert e.value.code == -4
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        before = ctx.render_frame(W, H, max_depth=D)
+        assert ctx.stats()["accel"] == 0
+        with pytest.raises(rt.RtError) as e:
+            ctx.update_mesh_vertices(spec.verts[:-1])
+        assert e.value.code == -4
+        with pytest.raises(rt.RtError) as e:
+            ctx.update_triangles(np.zeros((spec.n_tris + 1, 9), np.float32))
+        assert e.value.code == -4
+        again = ctx.render_frame(W, H, max_depth=D)
+        assert np.array_equal(before["rgb8"], again["rgb8"])
+        v = _moved(spec.verts, 2)
+        ctx.update_mesh_vertices(v)
+        g = ctx.render_frame(W, H, max_depth=D)
+    r = to_oracle(SceneSpecCopy(spec, v)).render(W, H, max_depth=D, cam=ocam(cam))
+    assert_parity(compare(g, r))
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
@@ -537,6 +618,26 @@ def test_host_multi_frame_draw_loop_rerenders_with_a_moving_camera():
     r = to_oracle(spec).render(320, 240, max_depth=3, cam=ocam(cam), threads=8)
     d = np.abs(img.astype(int) - r["rgb8"].astype(int)).max(-1)
     assert (d > 1).mean() < 0.001
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_wobble_moves_the_mesh_between_ticks_through_the_refit():
+    """--wobble A: every tick the mesh vertices move and rt_update_mesh_vertices refits the tree.  The
+    run reports the refit time; its frame differs from the rigid run's, whose camera is the same.  (What
+    a refitted frame must equal is checked at the library level, against a fresh build and the oracle.)"""
+    v, i, _ = scenes.atrium_mesh(detail=0.25)
+    tris = [tuple(int(x) for x in i[k:k + 3]) for k in range(0, len(i), 3)]
+    with tempfile.TemporaryDirectory() as td:
+        obj = os.path.join(td, "m.obj")
+        scenes.write_obj(obj, v, tris)
+        frames = {}
+        for name, extra in (("rigid", []), ("wobble", ["--wobble", "0.3"])):
+            ppm = os.path.join(td, name + ".ppm")
+            out = subprocess.run([HOST_BIN, "--obj", obj, "--no-mirror", "--frames", "3", "--width", "320", "--height", "240",
+                                  "--out", ppm, "--raw-order"] + extra, check=True, capture_output=True, text=True, timeout=120).stdout
+            frames[name] = _read_ppm(ppm)[0]
+            assert ("refit" in out) == (name == "wobble"), out
+    assert (frames["rigid"] != frames["wobble"]).any(-1).mean() > 0.02
 
 
 # ------------------------------------------------------------------ many lights / no lights through the LBVH stages
