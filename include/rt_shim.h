@@ -140,6 +140,15 @@ int rt_set_triangles(rt_ctx *ctx, const float *tri_verts, int n_tris, const rt_m
 int rt_set_triangle_materials(rt_ctx *ctx, const rt_material *mats, int n_mats,
                               const int32_t *tri_material, int n_tris);
 
+/* Opt-in shading normals from the `vn` statements the reference parses and never uses
+ * (objloader.cpp:56-63; main.cpp:222-226 drops them; Triangle::GetNormal, main.cpp:131-134, returns the
+ * geometric normal).  corner_normals = n_tris x (at v1, at v2, at v3) x (x,y,z).  With them set, the
+ * normal of a triangle hit is normalize(n1*(1-u-v) + n2*u + n3*v) with u, v as Triangle::Raycast computes
+ * them (main.cpp:119, 124); a triangle whose nine values are all zero keeps its geometric normal.  This
+ * departs from the reference's image, so it is off until called; NULL turns it off again.  Replaced
+ * meshes (rt_set_mesh / rt_set_triangles) drop the normals; rt_update_* keep them. */
+int rt_set_triangle_normals(rt_ctx *ctx, const float *corner_normals, int n_tris);
+
 /* Moving geometry for the per-tick re-render (draw(dt), main.cpp:284-287, glwt.mm:68-82; the reference
  * itself redraws one static frame): new positions for the triangles already loaded, same count and
  * order.  Materials and the hierarchy's topology stay; the Triangle constructor (main.cpp:104-107) runs

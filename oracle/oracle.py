@@ -58,6 +58,7 @@ def lib():
         L.rto_scene_create.argtypes = [C.POINTER(Prim), C.c_int]
         L.rto_scene_destroy.argtypes = [C.c_void_p]
         L.rto_scene_build_bvh.argtypes = [C.c_void_p]
+        L.rto_scene_set_corner_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rto_render.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 9 + [C.c_void_p] * 5
         L.rto_raytrace.argtypes = [C.c_void_p, f3, f3, C.c_int, C.c_int, C.c_int, f3,
                                    C.POINTER(C.c_int32), f3, C.c_void_p]
@@ -149,6 +150,15 @@ class Scene:
         if lib().rto_scene_build_bvh(self._h) != 0:
             raise RuntimeError("rto_scene_build_bvh failed")
         self.has_bvh = True
+
+    def set_corner_normals(self, vn):
+        """Opt-in shading normals, (n_tris, 3, 3) in scene order; None = the reference's geometric normals."""
+        if vn is None:
+            lib().rto_scene_set_corner_normals(self._h, None, 0)
+            return
+        a = np.ascontiguousarray(vn, dtype=np.float32).reshape(-1, 9)
+        if lib().rto_scene_set_corner_normals(self._h, a.ctypes.data, a.shape[0]) != 0:
+            raise RuntimeError("rto_scene_set_corner_normals: count mismatch")
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -177,6 +177,9 @@ struct rto_scene {
     /* BVH */
     bvh_node *nodes; int n_nodes;
     int *tri_order;                 /* prim ids, leaf order */
+    /* opt-in shading normals (not in the reference): 9 floats per triangle, by triangle ordinal */
+    float *vn;
+    int *tri_ordinal;               /* prim id -> index among the triangles */
 };
 
 rto_scene *rto_scene_create(const rto_prim *prims, int n)
@@ -202,7 +205,26 @@ void rto_scene_destroy(rto_scene *s)
     if (!s) return;
     free(s->prims); free(s->lights); free(s->linear); free(s->tris);
     free(s->nodes); free(s->tri_order);
+    free(s->vn); free(s->tri_ordinal);
     free(s);
+}
+
+/* Shading normals for the triangles, in scene order: n_tris x (at v1, at v2, at v3) x (x,y,z).  The
+ * reference parses `vn` and drops it (objloader.cpp:56-63, main.cpp:222-226), so this has no reference
+ * behaviour to match; the rule restated here is the one the HIP path documents.  NULL switches back. */
+int rto_scene_set_corner_normals(rto_scene *s, const float *vn, int n_tris)
+{
+    free(s->vn); s->vn = NULL;
+    free(s->tri_ordinal); s->tri_ordinal = NULL;
+    if (!vn) return 0;
+    if (n_tris != s->n_tris || n_tris == 0) return -1;
+    s->vn = (float *)malloc(sizeof(float) * 9 * (size_t)n_tris);
+    s->tri_ordinal = (int *)malloc(sizeof(int) * (size_t)s->n_prims);
+    if (!s->vn || !s->tri_ordinal) return -1;
+    memcpy(s->vn, vn, sizeof(float) * 9 * (size_t)n_tris);
+    for (int i = 0; i < s->n_prims; i++) s->tri_ordinal[i] = -1;
+    for (int k = 0; k < s->n_tris; k++) s->tri_ordinal[s->tris[k]] = k;
+    return 0;
 }
 
 typedef struct { float c[3]; int id; } bvh_item;
@@ -401,6 +423,24 @@ static v3 raytrace(const rto_scene *s, v3 ro, v3 rd, int depth, int max_depth, i
     v3 col = V(0.0f, 0.0f, 0.0f);
     v3 pos = vadd(ro, vmuls(rd, h.t));                                          /* main.cpp:163 */
     v3 N = prim_normal(np, pos);                                                /* main.cpp:164 */
+    if (s->vn && np->kind == RTO_TRIANGLE) {
+        /* N = normalize(n1*(1-u-v) + n2*u + n3*v), u and v as in Triangle::Raycast (main.cpp:110-124);
+         * nine zeros keep the geometric normal */
+        const float *q = s->vn + 9 * (size_t)s->tri_ordinal[h.id];
+        int any = 0;
+        for (int k = 0; k < 9; k++) any |= q[k] != 0.0f;
+        if (any) {
+            v3 e1 = vld(np->b), e2 = vld(np->c);
+            v3 P = vcross(rd, e2);
+            float invdet = 1.0f / vdot(e1, P);
+            v3 T = vsub(ro, vld(np->a));
+            float u = vdot(T, P) * invdet;
+            v3 Q = vcross(T, e1);
+            float v = vdot(rd, Q) * invdet;
+            float w = 1.0f - u - v;
+            N = vnormalize(vadd(vadd(vmuls(vld(q), w), vmuls(vld(q + 3), u)), vmuls(vld(q + 6), v)));
+        }
+    }
     v3 Mc = vld(np->mat.color);
 
     if (np->is_light) {

@@ -79,6 +79,12 @@ void rto_scene_destroy(rto_scene *s);
  * result equals brute force unless a padded box wrongly culls a hit. */
 int rto_scene_build_bvh(rto_scene *s);
 
+/* Opt-in shading normals (no reference behaviour: the reference parses `vn` and drops it,
+ * objloader.cpp:56-63, main.cpp:222-226).  vn = n_tris x 3 corners x (x,y,z), triangles in scene
+ * order; NULL switches back to Triangle::GetNormal (main.cpp:131-134).  Returns 0, or -1 on a
+ * count mismatch. */
+int rto_scene_set_corner_normals(rto_scene *s, const float *vn, int n_tris);
+
 /* Trace one ray exactly as raytrace() (main.cpp:144-217) with `max_depth` in place
  * of the constant at main.cpp:18.  Outputs colour and the nearest primitive / t of
  * THIS ray (hit_id -1 on a miss). */

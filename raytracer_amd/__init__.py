@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_option", "rt_set_analytic",
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
-    "rt_update_triangles", "rt_update_mesh_vertices",
+    "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals",
 )
 
 
@@ -163,6 +163,7 @@ def load_library():
     L.rt_set_mesh.argtypes = [vp, vp, i32, vp, i32, C.POINTER(Material)]
     L.rt_set_triangles.argtypes = [vp, vp, i32, C.POINTER(Material)]
     L.rt_set_triangle_materials.argtypes = [vp, C.POINTER(Material), i32, vp, i32]
+    L.rt_set_triangle_normals.argtypes = [vp, vp, i32]
     L.rt_update_triangles.argtypes = [vp, vp, i32]
     L.rt_update_mesh_vertices.argtypes = [vp, vp, i32]
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
@@ -232,6 +233,14 @@ class Context:
         tm = np.ascontiguousarray(tri_material, dtype=np.int32).reshape(-1)
         arr = (Material * len(mats))(*mats)
         self._check(self.L.rt_set_triangle_materials(self._h, arr, len(mats), tm.ctypes.data, tm.shape[0]))
+
+    def set_triangle_normals(self, corner_normals):
+        """rt_set_triangle_normals: (n_tris, 3, 3) shading normals at v1, v2, v3; None = geometric normals."""
+        if corner_normals is None:
+            self._check(self.L.rt_set_triangle_normals(self._h, None, 0))
+            return
+        v = np.ascontiguousarray(corner_normals, dtype=np.float32).reshape(-1, 9)
+        self._check(self.L.rt_set_triangle_normals(self._h, v.ctypes.data, v.shape[0]))
 
     def update_triangles(self, tri_verts):
         """rt_update_triangles: moved vertices for the loaded triangles (same count and order)."""

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PS_WAVES_
                     const int id = __float_as_int(h.y);
                     if (id >= 0 && id < sc.n_analytic + sc.n_tris) {
                         pos = add(f3(qo), muls(f3(qd), h.x));                             // main.cpp:163
-                        const Surface sf = surface_at(sc, id, pos);                       // main.cpp:164
+                        const Surface sf = surface_at(sc, id, pos, f3(qo), f3(qd));       // main.cpp:164
                         lit = !sf.emissive;                                               // main.cpp:166
                         spawn = lit && sf.kr > 0.0f && plevel < A.max_depth;              // main.cpp:208
                         if (spawn) R = mirror_dir(f3(qd), sf.N);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
             F3 pos = o, R = d;
             if (id >= 0) {
                 pos = add(o, muls(d, t));                                                 // main.cpp:163
-                const Surface s = surface_at(sc, id, pos);                                // main.cpp:164
+                const Surface s = surface_at(sc, id, pos, o, d);                          // main.cpp:164
                 if (k == 0 && A.normal) { A.normal[3 * p] = s.N.x; A.normal[3 * p + 1] = s.N.y; A.normal[3 * p + 2] = s.N.z; }
                 if (s.emissive) {
                     col = s.Mc;                                                           // main.cpp:166-167

@@ -148,10 +148,32 @@ __device__ __forceinline__ PixelRay primary_ray(const DevCamera &cam, int W, int
     return r;
 }
 
-// Surface data of a hit primitive: normal (main.cpp:70-73, 94-97, 131-134) and material.
+// Opt-in shading normal of a triangle (the reference parses `vn` and never uses it, objloader.cpp:56-63,
+// main.cpp:222-226): the corner normals weighted by the barycentrics of Triangle::Raycast (main.cpp:110-124),
+// N = normalize(n1*(1-u-v) + n2*u + n3*v), all in the reference's vec3 operators.  A triangle whose three
+// corner normals are all zero keeps its geometric normal.
+__device__ __forceinline__ F3 smooth_normal(const DevScene &sc, int tri, F3 o, F3 d, F3 flat)
+{
+    const F3 n1 = f3(sc.tri_vn[3 * (size_t)tri]), n2 = f3(sc.tri_vn[3 * (size_t)tri + 1]), n3 = f3(sc.tri_vn[3 * (size_t)tri + 2]);
+    if (n1.x == 0.0f && n1.y == 0.0f && n1.z == 0.0f && n2.x == 0.0f && n2.y == 0.0f && n2.z == 0.0f && n3.x == 0.0f &&
+        n3.y == 0.0f && n3.z == 0.0f)
+        return flat;
+    const F3 v1 = f3(sc.tri_mt[3 * (size_t)tri]), e1 = f3(sc.tri_mt[3 * (size_t)tri + 1]), e2 = f3(sc.tri_mt[3 * (size_t)tri + 2]);
+    const F3 P = cross(d, e2);                          // main.cpp:111
+    const float invdet = 1.0f / dot(e1, P);             // main.cpp:112, 116
+    const F3 T = sub(o, v1);                            // main.cpp:118
+    const float u = dot(T, P) * invdet;                 // main.cpp:119
+    const F3 Q = cross(T, e1);                          // main.cpp:123
+    const float v = dot(d, Q) * invdet;                 // main.cpp:124
+    const float w = 1.0f - u - v;
+    return normalize(add(add(muls(n1, w), muls(n2, u)), muls(n3, v)));
+}
+
+// Surface data of a hit primitive: normal (main.cpp:70-73, 94-97, 131-134) and material.  (o, d) is the
+// ray that hit; only the opt-in shading normals read it.
 struct Surface { F3 N, Mc; float kr, kd, ks; bool emissive; };
 
-__device__ __forceinline__ Surface surface_at(const DevScene &sc, int id, F3 pos)
+__device__ __forceinline__ Surface surface_at(const DevScene &sc, int id, F3 pos, F3 o, F3 d)
 {
     Surface s;
     if (id < sc.n_analytic) {
@@ -163,6 +185,7 @@ __device__ __forceinline__ Surface surface_at(const DevScene &sc, int id, F3 pos
     } else {
         float4 tn = sc.tri_n[id - sc.n_analytic];
         s.N = f3(tn);
+        if (sc.tri_vn) s.N = smooth_normal(sc, id - sc.n_analytic, o, d, s.N);
         const DevMaterial m = sc.mats[__float_as_int(tn.w)];
         s.Mc = mk(m.cr, m.cg, m.cb);
         s.kr = m.reflect; s.kd = m.diffuse; s.ks = m.spec;

@@ -73,6 +73,7 @@ struct DevScene {
     const int32_t *lights;         // [n_lights] analytic ids with is_light, scene order
     const float4 *tri_mt;          // [n_tris*3] original order: (v1,·) (e1,·) (e2,·)
     const float4 *tri_n;           // [n_tris] (N.xyz, material index as int bits)
+    const float4 *tri_vn;          // [n_tris*3] shading normals at v1, v2, v3, or null: geometric normals (the reference)
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
     const BvhNodeQ *qnodes;        // same tree, quantised boxes

@@ -31,6 +31,7 @@ struct rt_ctx {
     float4 *d_tri_mt = nullptr, *d_tri_n = nullptr;
     int n_tris = 0;
     int32_t *d_indices = nullptr;   // kept from rt_set_mesh for rt_update_mesh_vertices
+    float4 *d_tri_vn = nullptr;     // opt-in shading normals, 3 per triangle (rt_set_triangle_normals)
     int n_mesh_verts = 0;
     DevMaterial *d_mats = nullptr;
     int n_mats = 0;
@@ -98,6 +99,8 @@ void free_triangles(rt_ctx *c)
     if (c->d_tri_n) (void)hipFree(c->d_tri_n);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_indices) (void)hipFree(c->d_indices);
+    if (c->d_tri_vn) (void)hipFree(c->d_tri_vn);
+    c->d_tri_vn = nullptr;
     c->d_tri_mt = c->d_tri_n = nullptr;
     c->d_mats = nullptr;
     c->d_indices = nullptr;
@@ -313,7 +316,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
 
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
-    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.mats = c->d_mats;
+    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.mats = c->d_mats;
     sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
 
@@ -679,6 +682,33 @@ int rt_set_triangle_materials(rt_ctx *c, const rt_material *mats, int n_mats, co
     if (c->d_mats) (void)hipFree(c->d_mats);
     c->d_mats = nm;
     c->n_mats = n_mats;
+    return RT_OK;
+}
+
+int rt_set_triangle_normals(rt_ctx *c, const float *corner_normals, int n_tris)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (!corner_normals) {                      // back to the reference's geometric normals
+        if (c->d_tri_vn) (void)hipFree(c->d_tri_vn);
+        c->d_tri_vn = nullptr;
+        c->state_version++;
+        return RT_OK;
+    }
+    if (n_tris != c->n_tris || c->n_tris == 0) return fail(RT_E_STATE, "triangle count does not match the loaded mesh");
+    std::vector<float4> h(3 * (size_t)n_tris);
+    for (size_t k = 0; k < 3 * (size_t)n_tris; k++)
+        h[k] = make_float4(corner_normals[3 * k], corner_normals[3 * k + 1], corner_normals[3 * k + 2], 0.0f);
+    float4 *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(float4) * h.size()) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(normals)");
+    if (hipMemcpy(d, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(RT_E_DEVICE, "upload normals");
+    }
+    if (c->d_tri_vn) (void)hipFree(c->d_tri_vn);
+    c->d_tri_vn = d;
+    c->state_version++;
     return RT_OK;
 }
 

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             } else {
                 float4 tn = sc.tri_n[best_id - sc.n_analytic];                  // main.cpp:133
                 N = f3(tn);
+                if (sc.tri_vn) N = smooth_normal(sc, best_id - sc.n_analytic, o, d, N);
                 const DevMaterial m = sc.mats[__float_as_int(tn.w)];
                 Mc = mk(m.cr, m.cg, m.cb);
                 kr = m.reflect; kd = m.diffuse; ks = m.spec;

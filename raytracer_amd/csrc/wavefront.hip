@@ -504,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             bool spawn = false;
             F3 R = r.d;
             if (lit && A.level < A.max_depth) {
-                const Surface s = surface_at(sc, r.id, pos);                              // main.cpp:164
+                const Surface s = surface_at(sc, r.id, pos, r.o, r.d);                             // main.cpp:164
                 spawn = s.kr > 0.0f;                                                      // main.cpp:208
                 if (spawn) R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));            // main.cpp:210
             }

@@ -7,10 +7,11 @@
 //   raytracer [--out frame.ppm] [--raw-order] [--pfm frame.pfm] [--ids ids.bin]
 //             [--width W] [--height H] [--depth D] [--obj mesh.obj] [--mesh-reflect K]
 //             [--no-mirror] [--no-floor] [--device N] [--dump-obj mesh.obj]
-//             [--relaxed] [--exr frame.exr] [--frames N] [--wobble A] [--dump-obj-relaxed mesh.obj]
+//             [--relaxed] [--exr frame.exr] [--frames N] [--wobble A] [--smooth] [--dump-obj-relaxed mesh.obj]
 //
 // --relaxed reads the OBJ with the tolerant parser and takes materials from its .mtl files;
 // --frames N re-renders from draw(dt) with the camera swinging sideways, N - 1 more times;
+// --smooth (with --relaxed) shades with the file's `vn` normals, interpolated (off: the reference's flat normals);
 // --wobble A also sways the mesh vertices by up to A units per tick (the hierarchy is refitted).
 #include <cmath>
 #include <cstdio>
@@ -29,7 +30,7 @@ namespace {
 struct Config {
     int imageWidth = 800, imageHeight = 600, maxDepth = 3;   // main.cpp:18
     std::string out = "frame.ppm", pfm, ids, obj, exr;
-    bool raw_order = false, mirror = true, floor = true, relaxed = false;
+    bool raw_order = false, mirror = true, floor = true, relaxed = false, smooth = false;
     int frames = 1;
     float mesh_reflect = 0.0f;                               // main.cpp:34: meshes do not reflect
     float wobble = 0.0f;
@@ -101,8 +102,17 @@ bool LoadModel(const char *model)
                    "rt_set_mesh"))
             return false;
         if (m.tri_material.empty()) return true;
-        return check(rt_set_triangle_materials(ctx, mats.data(), (int)mats.size(), m.tri_material.data(), (int)m.tri_material.size()),
-                     "rt_set_triangle_materials");
+        if (!check(rt_set_triangle_materials(ctx, mats.data(), (int)mats.size(), m.tri_material.data(), (int)m.tri_material.size()),
+                   "rt_set_triangle_materials"))
+            return false;
+        if (cfg.smooth) {
+            std::vector<float> vn;
+            const int with = CornerNormals(m, vn);
+            printf("%d of %zu triangles carry vn normals\n", with, m.tri_material.size());
+            if (with > 0 && !check(rt_set_triangle_normals(ctx, vn.data(), (int)m.tri_material.size()), "rt_set_triangle_normals"))
+                return false;
+        }
+        return true;
     }
     std::vector<vec3> verts;
     std::vector<vec2> uvs;
@@ -258,6 +268,7 @@ static int dump_obj_relaxed(const char *path)
     for (const vec3 &p : m.vertices) printf("v %.9g %.9g %.9g\n", p.x, p.y, p.z);
     for (size_t i = 0; i < m.indices.size(); i++) printf("i %d\n", m.indices[i]);
     for (size_t i = 0; i < m.tri_material.size(); i++) printf("t %d\n", m.tri_material[i]);
+    for (size_t i = 0; i < m.normal_indices.size(); i++) printf("n %d %d\n", m.normal_indices[i], m.texcoord_indices[i]);
     for (const ObjMaterial &om : m.materials)
         printf("m %s|%.9g %.9g %.9g %.9g %.9g %.9g\n", om.name, om.reflect, om.diffuse, om.spec, om.color[0], om.color[1], om.color[2]);
     return 0;
@@ -286,6 +297,7 @@ int main(int argc, char *argv[])
         else if (a == "--dump-obj") return dump_obj(val());
         else if (a == "--dump-obj-relaxed") return dump_obj_relaxed(val());
         else if (a == "--relaxed") cfg.relaxed = true;
+        else if (a == "--smooth") cfg.smooth = true;
         else if (a == "--exr") cfg.exr = val();
         else if (a == "--frames") cfg.frames = atoi(val());
         else if (a == "--wobble") cfg.wobble = (float)atof(val());

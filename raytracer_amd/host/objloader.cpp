@@ -192,7 +192,18 @@ bool LoadModelEx(const char *objFile, ObjModel &out)
     int cur_mat = 0;
     const char *p = text.data(), *fend = p + text.size();
     std::string key, t;
-    std::vector<int> corners;
+    std::vector<int> corners, corner_vt, corner_vn;
+    // a `v/vt/vn` reference: 1-based, negative = relative to the elements read so far, absent or 0 = none (-1)
+    auto side_index = [](const char *&cur, size_t count) -> int {
+        if (*cur != '/') return -1;
+        cur++;
+        char *endp = nullptr;
+        long v = strtol(cur, &endp, 10);
+        if (endp == cur) return -1;
+        cur = endp;
+        long idx = v > 0 ? v - 1 : (v < 0 ? (long)count + v : -1);
+        return idx < 0 || idx > 0x7ffffffe ? -1 : (int)idx;
+    };
     while (p < fend) {
         const char *eol = (const char *)memchr(p, '\n', (size_t)(fend - p));
         if (!eol) eol = fend;
@@ -222,7 +233,7 @@ bool LoadModelEx(const char *objFile, ObjModel &out)
                 if (!found) out.missing_materials++;
             }
         } else if (key == "f") {
-            corners.clear();
+            corners.clear(); corner_vt.clear(); corner_vn.clear();
             bool ok = true;
             while (token(q, eol, t)) {
                 char *endp = nullptr;
@@ -231,10 +242,15 @@ bool LoadModelEx(const char *objFile, ObjModel &out)
                 long idx = v > 0 ? v - 1 : (long)out.vertices.size() + v;   // negative: relative to the vertices so far
                 if (idx < 0 || idx > 0x7ffffffe) { ok = false; break; }      // positive ones may point ahead: checked at the end
                 corners.push_back((int)idx);
+                const char *side = endp;
+                corner_vt.push_back(side_index(side, out.texcoords.size()));
+                corner_vn.push_back(side_index(side, out.normals.size()));
             }
             if (!ok || corners.size() < 3) { out.dropped_faces++; continue; }
             for (size_t k = 1; k + 1 < corners.size(); k++) {   // fan around corner 0, as objloader.cpp:90-99 does for quads
                 out.indices.push_back(corners[0]); out.indices.push_back(corners[k]); out.indices.push_back(corners[k + 1]);
+                out.normal_indices.push_back(corner_vn[0]); out.normal_indices.push_back(corner_vn[k]); out.normal_indices.push_back(corner_vn[k + 1]);
+                out.texcoord_indices.push_back(corner_vt[0]); out.texcoord_indices.push_back(corner_vt[k]); out.texcoord_indices.push_back(corner_vt[k + 1]);
                 out.tri_material.push_back(cur_mat);
             }
         }
@@ -246,9 +262,34 @@ bool LoadModelEx(const char *objFile, ObjModel &out)
         const int a = out.indices[3 * tri], b = out.indices[3 * tri + 1], c = out.indices[3 * tri + 2];
         if (a >= nv || b >= nv || c >= nv) { out.dropped_faces++; continue; }
         out.indices[3 * kept] = a; out.indices[3 * kept + 1] = b; out.indices[3 * kept + 2] = c;
+        for (int k = 0; k < 3; k++) {
+            const int vn = out.normal_indices[3 * tri + k], vt = out.texcoord_indices[3 * tri + k];
+            out.normal_indices[3 * kept + k] = vn < (int)out.normals.size() ? vn : -1;        // may have pointed ahead, too
+            out.texcoord_indices[3 * kept + k] = vt < (int)out.texcoords.size() ? vt : -1;
+        }
         out.tri_material[kept++] = out.tri_material[tri];
     }
     out.indices.resize(3 * kept);
+    out.normal_indices.resize(3 * kept);
+    out.texcoord_indices.resize(3 * kept);
     out.tri_material.resize(kept);
     return true;
+}
+
+int CornerNormals(const ObjModel &m, std::vector<float> &out)
+{
+    const size_t n_tris = m.indices.size() / 3;
+    out.assign(9 * n_tris, 0.0f);
+    int with = 0;
+    for (size_t t = 0; t < n_tris; t++) {
+        const int a = m.normal_indices[3 * t], b = m.normal_indices[3 * t + 1], c = m.normal_indices[3 * t + 2];
+        if (a < 0 || b < 0 || c < 0) continue;
+        const int ix[3] = { a, b, c };
+        for (int k = 0; k < 3; k++) {
+            const vec3 &n = m.normals[(size_t)ix[k]];
+            out[9 * t + 3 * k] = n.x; out[9 * t + 3 * k + 1] = n.y; out[9 * t + 3 * k + 2] = n.z;
+        }
+        with++;
+    }
+    return with;
 }

@@ -34,6 +34,8 @@ struct ObjModel {
     std::vector<vec2> texcoords;
     std::vector<vec3> normals;
     std::vector<int> indices;              // 3 per triangle, 0-based positions
+    std::vector<int> normal_indices;       // 3 per triangle, 0-based into normals, -1 where the corner names none
+    std::vector<int> texcoord_indices;     // 3 per triangle, 0-based into texcoords, -1 where the corner names none
     std::vector<int> tri_material;         // 1 per triangle, index into materials
     std::vector<ObjMaterial> materials;    // [0] is the reference's default Material()
     int dropped_faces = 0;                 // faces with out-of-range or unparsable corners
@@ -46,3 +48,8 @@ struct ObjModel {
 //   models) -> reflect = largest Ks component, or 1 if Ks is absent;  the non-standard statement
 //   `reflect k` sets the coefficient directly and wins.
 bool LoadModelEx(const char *objFile, ObjModel &out);
+
+// The `vn` normals the reference parses and drops (objloader.cpp:56-63, main.cpp:222-226) in the layout
+// of rt_set_triangle_normals: 9 floats per triangle; a triangle with a corner that names no normal
+// gets nine zeros (= keep the geometric normal).  Returns how many triangles carry normals.
+int CornerNormals(const ObjModel &m, std::vector<float> &out);

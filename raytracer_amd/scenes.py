@@ -168,6 +168,34 @@ def instance_grid(verts, indices, tri_mat, nx, nz, dx, dz):
     return np.concatenate(V).astype(np.float32), np.concatenate(I).astype(np.int32), np.concatenate(M)
 
 
+def uv_sphere(center=(0.0, 0.0, 0.0), radius=1.0, n_lat=12, n_lon=24):
+    """A latitude/longitude sphere: verts (n,3), indices (3m,), unit vertex normals (n,3)."""
+    pts = [(0.0, 1.0, 0.0)]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2.0 * np.pi * j / n_lon
+            pts.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    pts.append((0.0, -1.0, 0.0))
+    nrm = np.asarray(pts, np.float64)
+    ring = lambda i, j: 1 + (i - 1) * n_lon + j % n_lon
+    idx = []
+    for j in range(n_lon):
+        idx += [0, ring(1, j + 1), ring(1, j)]
+        idx += [len(pts) - 1, ring(n_lat - 1, j), ring(n_lat - 1, j + 1)]
+    for i in range(1, n_lat - 1):
+        for j in range(n_lon):
+            a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j + 1), ring(i + 1, j)
+            idx += [a, b, c, a, c, d]
+    verts = (nrm * radius + np.asarray(center, np.float64)).astype(np.float32)
+    return verts, np.asarray(idx, np.int32), nrm.astype(np.float32)
+
+
+def corner_normals(vertex_normals, indices):
+    """(n_tris, 3, 3): the vertex normal at each triangle corner, the layout of rt_set_triangle_normals."""
+    return np.asarray(vertex_normals, np.float32)[np.asarray(indices, np.int64)].reshape(-1, 3, 3)
+
+
 def flatten(verts, indices):
     """main.cpp:228-231 on the host: (n_tris, 9) array of v1,v2,v3."""
     return np.asarray(verts, np.float32)[np.asarray(indices).reshape(-1, 3)].reshape(-1, 9)

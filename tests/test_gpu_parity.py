@@ -15,8 +15,8 @@ import tempfile
 import numpy as np
 import pytest
 
-from common import (GOLDEN, O, ROOT, atrium_spec, compare, cube_spec, golden_cases, ocam, rt, scenes, soup_spec,
-                    stock_spec, to_oracle, to_product)
+from common import (GOLDEN, O, ROOT, atrium_spec, compare, cube_spec, golden_cases, lcg_floats, ocam, rt, scenes, soup_spec,
+                    stock_analytic, stock_spec, to_oracle, to_product)
 
 pytestmark = pytest.mark.gpu
 
@@ -411,6 +411,83 @@ def test_vertex_update_of_a_linear_scan_scene_and_count_mismatches():
     assert_parity(compare(g, r))
 
 
+# ------------------------------------------------------------------ opt-in shading normals
+def _smooth_scene():
+    """A mirror-ish triangle sphere and a diffuse one with their vertex normals, and a few loose
+    triangles: half of those with arbitrary corner normals, half with nine zeros (geometric normal)."""
+    from common import SceneSpec
+    v1, i1, n1 = scenes.uv_sphere((-1.6, -1.0, 1.0), 1.5, 9, 14)
+    v2, i2, n2 = scenes.uv_sphere((1.8, -0.5, 2.0), 1.2, 7, 10)
+    loose = soup_spec(n_tris=10, seed=77)
+    v = np.concatenate([v1, v2, loose.verts])
+    i = np.concatenate([i1, i2 + len(v1), loose.indices + len(v1) + len(v2)])
+    vn = np.concatenate([scenes.corner_normals(n1, i1), scenes.corner_normals(n2, i2),
+                         (lcg_floats(90, 5).reshape(10, 3, 3) - 0.5).astype(np.float32)])
+    vn[-5:] = 0.0
+    mats = [(0.6, 0.8, 1.0, (0.9, 0.9, 1.0)), (0.0, 1.0, 1.0, (1.0, 0.6, 0.3)), (0.3, 1.0, 0.5, (0.4, 0.9, 0.5))]
+    tm = np.concatenate([np.zeros(len(i1) // 3), np.ones(len(i2) // 3), np.full(10, 2)]).astype(np.int32)
+    return SceneSpec(stock_analytic(mirror=False), v, i, mats=mats, tri_material=tm), vn
+
+
+@pytest.mark.parametrize("accel,pipeline", [(rt.ACCEL_LINEAR, 0), (rt.ACCEL_LBVH, rt.PIPELINE_FUSED),
+                                            (rt.ACCEL_LBVH, rt.PIPELINE_WAVEFRONT), (rt.ACCEL_LBVH, rt.PIPELINE_PERSISTENT)])
+def test_shading_normals_match_the_oracle_rule_in_every_pipeline(accel, pipeline):
+    """rt_set_triangle_normals: normals interpolated with Triangle::Raycast's own u, v.  The reference has
+    no such feature (parity unpinned); the check is against the oracle's statement of the same rule, to
+    the usual bar: ids and ray counts exact, colours within the tolerance.  Turning it off restores the
+    reference image bit for bit; vertex updates keep the normals, a new mesh drops them."""
+    spec, vn = _smooth_scene()
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 160, 120, 3
+    osc = to_oracle(spec)
+    r_flat = osc.render(W, H, max_depth=D, cam=ocam(cam))
+    osc.set_corner_normals(vn)
+    r_smooth = osc.render(W, H, max_depth=D, cam=ocam(cam))
+    assert (r_flat["rgb8"] != r_smooth["rgb8"]).any(-1).mean() > 0.05
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, accel)
+        ctx.set_option(rt.OPT_PIPELINE, pipeline)
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        flat = ctx.render_frame(W, H, max_depth=D)
+        assert_parity(compare(flat, r_flat))
+        ctx.set_triangle_normals(vn)
+        g = ctx.render_frame(W, H, max_depth=D)
+        assert_parity(compare(g, r_smooth))
+        assert rays(ctx.stats()) == orays(r_smooth)
+        ctx.update_mesh_vertices(spec.verts)                       # same positions: normals must survive
+        g2 = ctx.render_frame(W, H, max_depth=D)
+        assert np.array_equal(g2["rgb32"].view(np.uint32), g["rgb32"].view(np.uint32))
+        with pytest.raises(rt.RtError) as e:
+            ctx.set_triangle_normals(vn[:-1])
+        assert e.value.code == -4
+        ctx.set_triangle_normals(None)
+        off = ctx.render_frame(W, H, max_depth=D)
+        assert np.array_equal(off["rgb32"].view(np.uint32), flat["rgb32"].view(np.uint32))
+        ctx.set_triangle_normals(vn)
+        to_product(ctx, spec)                                      # a new mesh: back to geometric normals
+        again = ctx.render_frame(W, H, max_depth=D)
+        assert np.array_equal(again["rgb32"].view(np.uint32), flat["rgb32"].view(np.uint32))
+
+
+def test_frame_planes_report_the_shading_normal_when_set():
+    spec, vn = _smooth_scene()
+    cam = rt.Camera(pitch=0.05)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        ctx.set_triangle_normals(vn)
+        g = ctx.render_frame_planes(160, 120, max_depth=1)
+    first = len(spec.analytic)
+    ball = (g["hit_id"] >= first) & (g["hit_id"] < first + 2 * 14 + 7 * 14 * 2)    # the first sphere's triangles
+    assert ball.sum() > 200
+    n = g["normal"][ball].astype(np.float64)
+    assert np.abs(np.linalg.norm(n, axis=1) - 1.0).max() < 1e-5
+    # interpolated normals of a sphere mesh vary smoothly: many distinct values, unlike the per-face normal
+    assert len(np.unique(np.round(n, 4), axis=0)) > 0.5 * ball.sum()
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
@@ -638,6 +715,36 @@ def test_host_wobble_moves_the_mesh_between_ticks_through_the_refit():
             frames[name] = _read_ppm(ppm)[0]
             assert ("refit" in out) == (name == "wobble"), out
     assert (frames["rigid"] != frames["wobble"]).any(-1).mean() > 0.02
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_smooth_flag_shades_with_the_vn_normals_of_the_file():
+    """--relaxed --smooth: the OBJ's `vn` normals reach rt_set_triangle_normals; the frame equals the
+    oracle's with the same corner normals (the float text round-trips exactly at %.9g)."""
+    from common import SceneSpec
+    v, i, n = scenes.uv_sphere((0.0, -1.0, 1.0), 2.0, 8, 12)
+    with tempfile.TemporaryDirectory() as td:
+        obj, ppm, ids = (os.path.join(td, x) for x in ("s.obj", "f.ppm", "ids.bin"))
+        with open(obj, "w") as f:
+            for p in v:
+                f.write("v %.9g %.9g %.9g\n" % tuple(p))
+            for p in n:
+                f.write("vn %.9g %.9g %.9g\n" % tuple(p))
+            for k in range(0, len(i), 3):
+                f.write("f " + " ".join("%d//%d" % (j + 1, j + 1) for j in i[k:k + 3]) + "\n")
+        out = subprocess.run([HOST_BIN, "--obj", obj, "--relaxed", "--smooth", "--no-mirror", "--width", "320", "--height", "240",
+                              "--out", ppm, "--raw-order", "--ids", ids], check=True, capture_output=True, text=True, timeout=120).stdout
+        img, _ = _read_ppm(ppm)
+        hid = np.fromfile(ids, np.int32).reshape(240, 320)
+    assert "%d of %d triangles carry vn normals" % (len(i) // 3, len(i) // 3) in out
+    spec = SceneSpec(stock_analytic(mirror=False), v, i, (0.0, 1.0, 1.0, (1.0, 1.0, 1.0)))
+    osc = to_oracle(spec)
+    osc.set_corner_normals(scenes.corner_normals(n, i))
+    r = osc.render(320, 240, max_depth=3, cam=ocam(rt.camera_for_width(320)))
+    assert np.array_equal(hid, r["hit_id"])
+    d = np.abs(img.astype(int) - r["rgb8"].astype(int)).max(-1)
+    assert d.max() <= 1 and (d == 0).mean() >= MIN_FRACTION
+    assert (hid >= 3).sum() > 2000
 
 
 # ------------------------------------------------------------------ many lights / no lights through the LBVH stages

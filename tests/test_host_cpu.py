@@ -192,3 +192,24 @@ def test_relaxed_loader_equals_the_strict_one_on_a_clean_file():
         rhead, rv, ri, rt_, rm = _dump_relaxed(p)
     assert np.array_equal(rv.reshape(-1), sv) and ri == si
     assert rt_ == [0] * (len(si) // 3) and rhead["dropped"] == 0 and len(rm) == 1
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_relaxed_loader_keeps_the_normal_and_texcoord_index_of_every_corner():
+    """`f v/vt/vn` (the reference keeps only v, objloader.cpp:75-78): per triangle corner the 0-based vn
+    and vt index, -1 where a corner names none, relative (negative) and forward references resolved,
+    an index beyond the file turned into -1; fan-split polygons carry their corners' indices along."""
+    text = ("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
+            "vn 0 0 1\nvn 0 1 0\nvt 0 0\nvt 1 1\n"
+            "f 1/1/1 2/2/2 3/1/1 4/2/2\n"          # quad -> (0,1,2) (0,2,3)
+            "f 1//-1 2//-2 3//3\n"                 # relative normals; normal 3 is defined below
+            "f 1/2 2/9 3\n"                        # texcoord only; 9 does not exist; bare corner
+            "vn 1 0 0\n")
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "n.obj")
+        open(p, "w").write(text)
+        out = subprocess.run([HOST_BIN, "--dump-obj-relaxed", p], check=True, capture_output=True, text=True).stdout.splitlines()
+    pairs = [tuple(int(x) for x in l.split()[1:]) for l in out if l.startswith("n ")]
+    assert pairs == [(0, 0), (1, 1), (0, 0),  (0, 0), (0, 0), (1, 1),
+                     (1, -1), (0, -1), (2, -1),
+                     (-1, 1), (-1, -1), (-1, -1)]

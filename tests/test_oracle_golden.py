@@ -140,3 +140,33 @@ def test_oracle_matches_live_reference_object_code():
     assert np.array_equal(got["hit_id"], want["hit_id"])
     assert np.array_equal(bits(got["rgb32"]), bits(want["rgb32"]))
     assert np.array_equal(bits(got["hit_t"]), bits(want["hit_t"]))
+
+
+def test_corner_normals_make_a_tessellated_sphere_shade_like_the_analytic_one():
+    """The opt-in shading normals have no reference behaviour to be pinned to; what can be checked is
+    the rule's purpose: a coarse triangle sphere with its vertex normals shades much closer to the
+    analytic sphere (main.cpp:70-73) than the same mesh with geometric normals, hit ids are untouched,
+    and nine zeros keep the geometric normal."""
+    from raytracer_amd import scenes
+    cam = O.camera((0.0, 0.0, -5.0), 0.05, -4.0, -3.0, 0.0)
+    W, H = 160, 120
+    lights = [O.sphere((2.0, 5.0, -4.0), 0.1, O.material(0.0, 1.0, 1.0, (0.9, 0.9, 0.9)), True)]
+    mat = O.material(0.0, 1.0, 0.0, (1.0, 1.0, 1.0))
+    v, i, n = scenes.uv_sphere((0.0, 0.0, 1.0), 2.0, 10, 20)
+    mesh = O.triangles_from_mesh(v, i, [mat])
+    sm = O.Scene(lights, mesh=mesh)
+    flat = sm.render(W, H, max_depth=0, cam=cam)
+    sm.set_corner_normals(scenes.corner_normals(n, i))
+    smooth = sm.render(W, H, max_depth=0, cam=cam)
+    exact = O.Scene(lights + [O.sphere((0.0, 0.0, 1.0), 2.0, mat)]).render(W, H, max_depth=0, cam=cam)
+    assert np.array_equal(flat["hit_id"], smooth["hit_id"])
+    inner = (flat["hit_id"] >= 1) & (exact["hit_id"] == 1)
+    assert inner.sum() > 1000
+    e_flat = np.abs(flat["rgb32"][inner] - exact["rgb32"][inner]).mean()
+    e_smooth = np.abs(smooth["rgb32"][inner] - exact["rgb32"][inner]).mean()
+    assert e_smooth < 0.25 * e_flat, (e_smooth, e_flat)
+    sm.set_corner_normals(np.zeros((len(i) // 3, 3, 3), np.float32))
+    zeros = sm.render(W, H, max_depth=0, cam=cam)
+    assert np.array_equal(zeros["rgb32"].view(np.uint32), flat["rgb32"].view(np.uint32))
+    sm.set_corner_normals(None)
+    assert np.array_equal(sm.render(W, H, max_depth=0, cam=cam)["rgb8"], flat["rgb8"])
