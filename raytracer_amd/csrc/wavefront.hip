@@ -35,10 +35,17 @@
 // and overflows to a global column for the rare deeper path.
 #include "rt_traverse.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
 
 namespace {
 
+#ifndef WF_TIMES
+#define WF_TIMES 0         // 1: a diagnostic build whose plain kernels also record per-wave clocks (see RT_WF_TIMES below)
+#endif
 #ifndef WF_STACK
 #define WF_STACK 16
 #endif
@@ -99,6 +106,7 @@ struct TraceArgs {
     int *overflow;                  // [WF_OVF][total_lanes]
     unsigned int total_lanes;
     FrameCounters *counters;
+    unsigned long long *wave_times; // diagnostic (RT_WF_TIMES): [wave][3] 100 MHz clock at start, when nothing was left to claim, at exit
 };
 
 // MODE 0: nearest hit of every ray of one queue (or of the camera rays, PRIMARY).
@@ -147,6 +155,8 @@ void k_trace(TraceArgs A)
     int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
     const unsigned int n_units = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0)) * (unsigned)A.n_regions * UPR;
     bool exhausted = n_units == 0;
+    unsigned long long t_start = 0, t_exhaust = 0;
+    if ((COUNT || WF_TIMES) && A.wave_times) t_start = t_exhaust = wall_clock64();
 
     auto push = [&](int v) {
         if (sp < WF_LDS_STACK) stack[sp * BLOCK] = v;
@@ -182,7 +192,10 @@ void k_trace(TraceArgs A)
                 const unsigned long long unit = (unsigned long long)k * (unsigned)n_shards + (unsigned)shard;
                 if (unit >= n_units) {
                     shard = shard + 1 == n_shards ? 0 : shard + 1;
-                    if (++probes >= max_probes) exhausted = true;
+                    if (++probes >= max_probes) {
+                        exhausted = true;
+                        if ((COUNT || WF_TIMES) && A.wave_times) t_exhaust = wall_clock64();
+                    }
                     continue;
                 }
                 const unsigned int u = (unsigned)unit;
@@ -389,6 +402,10 @@ void k_trace(TraceArgs A)
         }
     }
 
+    if ((COUNT || WF_TIMES) && A.wave_times && lane == 0) {
+        unsigned long long *w = A.wave_times + 3 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+        w[0] = t_start; w[1] = t_exhaust; w[2] = wall_clock64();
+    }
     if (COUNT) {
         unsigned int vals[3] = { tl.box, tl.tri, tl.analytic };
         for (int k = 0; k < 3; k++) {
@@ -613,6 +630,17 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     const int shade_grid = n_regions < num_cus * 8 ? n_regions : num_cus * 8;
     unsigned int *cursor = ws.trace_cursors;
     int launches = 0;
+    // Diagnostic: with RT_WF_TIMES set (and test counting on, or a -DWF_TIMES=1 build for undisturbed kernels)
+    // every wave of every traversal launch records when it started, when it found nothing left to claim and
+    // when it exited; a summary per launch goes to stderr.
+    const size_t tw_stride = 3 * (size_t)trace_grid * (BLOCK / 64);
+    unsigned long long *d_times = nullptr;
+    std::vector<int> tw_modes;
+    if ((count || WF_TIMES) && getenv("RT_WF_TIMES")) {
+        const size_t n = tw_stride * (size_t)(2 * (fp.max_depth + 2) * (n_chunks + 1));
+        if (hipMalloc((void **)&d_times, sizeof(unsigned long long) * n) == hipSuccess) (void)hipMemsetAsync(d_times, 0, sizeof(unsigned long long) * n, stream);
+        else d_times = nullptr;
+    }
     // device events around every traversal launch (for rt_stats.ms_traverse)
     size_t te = 0;
     auto tstamp = [&]() -> int {
@@ -664,6 +692,8 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         const bool primary = mode == 0 && level == 0;
         int grid = (primary && n_regions * UPR < trace_grid * (BLOCK / 64)) ? (n_regions * UPR + 3) / 4 : trace_grid;
         if (mode == 2 && grid > num_cus * WF_WAVES_EU_MIXED) grid = num_cus * WF_WAVES_EU_MIXED;   // resident blocks only
+        t.wave_times = d_times ? d_times + tw_stride * tw_modes.size() : nullptr;
+        tw_modes.push_back(mode);
         if (int rc = tstamp()) return rc;
         if (primary) launch_trace<0, true>(t, count, grid, stream);
         else if (mode == 0) launch_trace<0, false>(t, count, grid, stream);
@@ -695,6 +725,35 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
             if (int rc = launch_traversal(0, level + 1, 0)) return rc;
     }
     RT_HIP_CHECK(hipGetLastError(), err);
+    if (d_times) {
+        std::vector<unsigned long long> h(tw_stride * tw_modes.size());
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_times, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d_times);
+        for (size_t L = 0; L < tw_modes.size(); L++) {
+            std::vector<double> ex, en;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t w = 0; w < tw_stride / 3; w++) {
+                const unsigned long long *q = &h[L * tw_stride + 3 * w];
+                if (q[2] == 0) continue;
+                t0 = q[0] < t0 ? q[0] : t0;
+                t1 = q[2] > t1 ? q[2] : t1;
+            }
+            for (size_t w = 0; w < tw_stride / 3; w++) {
+                const unsigned long long *q = &h[L * tw_stride + 3 * w];
+                if (q[2] == 0) continue;
+                ex.push_back((double)(q[1] - t0) * 0.01);      // 100 MHz clock -> microseconds
+                en.push_back((double)(q[2] - t0) * 0.01);
+            }
+            std::sort(ex.begin(), ex.end());
+            std::sort(en.begin(), en.end());
+            if (ex.empty()) continue;
+            auto pct = [](const std::vector<double> &v, double p) { return v[(size_t)(p * (double)(v.size() - 1))]; };
+            fprintf(stderr, "[rt] launch %zu mode %d: %zu waves, span %.1f us; nothing left to claim at p10 %.1f p50 %.1f p90 %.1f max %.1f; exit at p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
+                    L, tw_modes[L], ex.size(), (double)(t1 - t0) * 0.01, pct(ex, 0.1), pct(ex, 0.5), pct(ex, 0.9), ex.back(), pct(en, 0.1),
+                    pct(en, 0.5), pct(en, 0.9), pct(en, 0.99), en.back());
+        }
+    }
     ws.trav_pairs = (int)(te / 2);
     // ---- every level's local colour, the fold and the outputs, one thread per pixel
     if (int rc = shade_all_launch(scene, cam, fp, ws.p_hits, ws.p_occ, occ_chunks, ws.records, ws.counters, d_rgb8, d_hit_id,
