@@ -354,6 +354,65 @@ __device__ __forceinline__ uint8_t quantise8(float c)
     return (f == f) ? (uint8_t)(int)f : (uint8_t)0;
 }
 
+// One level of one pixel's chain: the local colour of main.cpp:159-205 for the ray (o, d) whose nearest hit is
+// stored in plane k.  Returns whether the chain goes on (main.cpp:208) and, if so, the next ray (pos, R).
+struct LevelOut { F3 col, pos, R, Mc; float kr; int id; bool spawn; };
+
+__device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p, int k, F3 o, F3 d, int &id0, unsigned int &n_shadow)
+{
+    const DevScene &sc = A.sc;
+    LevelOut out;
+    const float2 h = A.hits[(size_t)k * (size_t)A.n_pixels + p];
+    const float t = h.x;
+    int id = __float_as_int(h.y);
+    if (id >= sc.n_analytic + sc.n_tris) id = -1;      // never index scene arrays with an id outside the scene
+    if (k == 0) {
+        id0 = id;
+        if (A.hit_t) A.hit_t[p] = t;
+        if (A.normal && id < 0) { A.normal[3 * p] = 0.f; A.normal[3 * p + 1] = 0.f; A.normal[3 * p + 2] = 0.f; }
+    }
+    F3 col = mk(0.f, 0.f, 0.f);                                                   // main.cpp:159-160
+    out.spawn = false;
+    out.pos = o; out.R = d;
+    out.Mc = mk(0.f, 0.f, 0.f); out.kr = 0.f;
+    if (id >= 0) {
+        const F3 pos = add(o, muls(d, t));                                        // main.cpp:163
+        const Surface s = surface_at(sc, id, pos, o, d);                          // main.cpp:164
+        out.pos = pos; out.Mc = s.Mc; out.kr = s.kr;
+        if (k == 0 && A.normal) { A.normal[3 * p] = s.N.x; A.normal[3 * p + 1] = s.N.y; A.normal[3 * p + 2] = s.N.z; }
+        if (s.emissive) {
+            col = s.Mc;                                                           // main.cpp:166-167
+        } else {
+            n_shadow += (unsigned)sc.n_lights;
+            unsigned int bits = 0;
+            for (int li = 0; li < sc.n_lights; li++) {                            // main.cpp:170-173
+                if ((li & 31) == 0) bits = A.occ[((size_t)k * A.n_chunks + (li >> 5)) * (size_t)A.n_pixels + p];
+                const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
+                const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));     // main.cpp:178
+                const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;     // main.cpp:175, 185
+                const F3 Lc = mk(lt_.cr, lt_.cg, lt_.cb);
+                if (s.kd > 0.0f) {                                                // main.cpp:191-195
+                    const float diffuse = dot(s.N, L) * s.kd;
+                    col = add(col, muls(muls(mulv(Lc, s.Mc), diffuse), shade));
+                }
+                if (s.ks > 0.0f) {                                                // main.cpp:198-204
+                    const F3 Rl = sub(L, muls(muls(s.N, dot(L, s.N)), 2.0f));
+                    const float dt = dot(d, Rl);
+                    if (dt > 0.0f)
+                        col = add(col, muls(muls(muls(mulv(Lc, s.Mc), pow20(dt)), s.ks), shade));
+                }
+            }
+            out.spawn = s.kr > 0.0f && k < A.max_depth;                           // main.cpp:208
+            if (out.spawn) out.R = mirror_dir(d, s.N);
+        }
+    }
+    out.col = col; out.id = id;
+    return out;
+}
+
+// REG_LEVELS > 0: the frame has at most that many levels and a pixel's local colours stay in registers
+// between the walk down its chain and the fold back up; 0: any depth, through the records plane.
+template <int REG_LEVELS>
 __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
 {
     __shared__ unsigned int s_stat[2];
@@ -369,71 +428,56 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
         const float offsetY = (float)y * A.cam.pitch + A.cam.off_y;                      // main.cpp:269
         F3 d = normalize(sub(mk(offsetX, offsetY, A.cam.plane_z), o));                    // main.cpp:270
         int last = 0, id0 = -1;
-        for (int k = 0;; k++) {
-            const float2 h = A.hits[(size_t)k * (size_t)A.n_pixels + p];
-            const float t = h.x;
-            int id = __float_as_int(h.y);
-            if (id >= sc.n_analytic + sc.n_tris) id = -1;      // never index scene arrays with an id outside the scene
-            if (k == 0) {
-                id0 = id;
-                if (A.hit_t) A.hit_t[p] = t;
-                if (A.normal && id < 0) { A.normal[3 * p] = 0.f; A.normal[3 * p + 1] = 0.f; A.normal[3 * p + 2] = 0.f; }
-            }
-            last = k;
-            F3 col = mk(0.f, 0.f, 0.f);                                                   // main.cpp:159-160
-            bool spawn = false;
-            F3 pos = o, R = d;
-            if (id >= 0) {
-                pos = add(o, muls(d, t));                                                 // main.cpp:163
-                const Surface s = surface_at(sc, id, pos, o, d);                          // main.cpp:164
-                if (k == 0 && A.normal) { A.normal[3 * p] = s.N.x; A.normal[3 * p + 1] = s.N.y; A.normal[3 * p + 2] = s.N.z; }
-                if (s.emissive) {
-                    col = s.Mc;                                                           // main.cpp:166-167
-                } else {
-                    n_shadow += (unsigned)sc.n_lights;
-                    unsigned int bits = 0;
-                    for (int li = 0; li < sc.n_lights; li++) {                            // main.cpp:170-173
-                        if ((li & 31) == 0) bits = A.occ[((size_t)k * A.n_chunks + (li >> 5)) * (size_t)A.n_pixels + p];
-                        const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
-                        const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));     // main.cpp:178
-                        const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;     // main.cpp:175, 185
-                        const F3 Lc = mk(lt_.cr, lt_.cg, lt_.cb);
-                        if (s.kd > 0.0f) {                                                // main.cpp:191-195
-                            const float diffuse = dot(s.N, L) * s.kd;
-                            col = add(col, muls(muls(mulv(Lc, s.Mc), diffuse), shade));
-                        }
-                        if (s.ks > 0.0f) {                                                // main.cpp:198-204
-                            const F3 Rl = sub(L, muls(muls(s.N, dot(L, s.N)), 2.0f));
-                            const float dt = dot(d, Rl);
-                            if (dt > 0.0f)
-                                col = add(col, muls(muls(muls(mulv(Lc, s.Mc), pow20(dt)), s.ks), shade));
-                        }
-                    }
-                    spawn = s.kr > 0.0f && k < A.max_depth;                               // main.cpp:208
-                    if (spawn) R = mirror_dir(d, s.N);
+        F3 col;
+        if (REG_LEVELS > 0) {
+            constexpr int NL = REG_LEVELS > 0 ? REG_LEVELS : 1;
+            F3 lc[NL], lm[NL];
+            float lk[NL];
+            bool alive = true;
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                lc[k] = mk(0.f, 0.f, 0.f); lm[k] = mk(0.f, 0.f, 0.f); lk[k] = 0.f;
+                if (alive) {
+                    const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow);
+                    lc[k] = L.col; lm[k] = L.Mc; lk[k] = L.kr;
+                    last = k;
+                    alive = L.spawn;
+                    if (alive) { n_reflect++; o = L.pos; d = L.R; }                       // main.cpp:211
                 }
             }
-            A.records[(size_t)k * (size_t)A.n_pixels + p] = make_float4(col.x, col.y, col.z, __int_as_float(id));
-            if (!spawn) break;
-            n_reflect++;
-            o = pos; d = R;                                                               // main.cpp:211
-        }
-        // fold deepest-first: col_k = local_k + (col_{k+1} * Mc_k) * kr_k               (main.cpp:212)
-        const float4 rl = A.records[(size_t)last * (size_t)A.n_pixels + p];
-        F3 col = mk(rl.x, rl.y, rl.z);
-        for (int k = last - 1; k >= 0; k--) {
-            const float4 rk = A.records[(size_t)k * (size_t)A.n_pixels + p];
-            const int id = __float_as_int(rk.w);
-            F3 Mc;
-            float kr;
-            if (id < sc.n_analytic) {
-                const DevAnalytic a = sc.analytic[id];
-                Mc = mk(a.cr, a.cg, a.cb); kr = a.reflect;
-            } else {
-                const DevMaterial m = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)];
-                Mc = mk(m.cr, m.cg, m.cb); kr = m.reflect;
+            // fold deepest-first: col_k = local_k + (col_{k+1} * Mc_k) * kr_k           (main.cpp:212)
+            col = mk(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = NL - 1; k >= 0; k--) {
+                if (k == last) col = lc[k];
+                else if (k < last) col = add(lc[k], muls(mulv(col, lm[k]), lk[k]));
             }
-            col = add(mk(rk.x, rk.y, rk.z), muls(mulv(col, Mc), kr));
+        } else {
+            for (int k = 0;; k++) {
+                const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow);
+                last = k;
+                A.records[(size_t)k * (size_t)A.n_pixels + p] = make_float4(L.col.x, L.col.y, L.col.z, __int_as_float(L.id));
+                if (!L.spawn) break;
+                n_reflect++;
+                o = L.pos; d = L.R;                                                       // main.cpp:211
+            }
+            // fold deepest-first: col_k = local_k + (col_{k+1} * Mc_k) * kr_k           (main.cpp:212)
+            const float4 rl = A.records[(size_t)last * (size_t)A.n_pixels + p];
+            col = mk(rl.x, rl.y, rl.z);
+            for (int k = last - 1; k >= 0; k--) {
+                const float4 rk = A.records[(size_t)k * (size_t)A.n_pixels + p];
+                const int id = __float_as_int(rk.w);
+                F3 Mc;
+                float kr;
+                if (id < sc.n_analytic) {
+                    const DevAnalytic a = sc.analytic[id];
+                    Mc = mk(a.cr, a.cg, a.cb); kr = a.reflect;
+                } else {
+                    const DevMaterial m = sc.mats[__float_as_int(sc.tri_n[id - sc.n_analytic].w)];
+                    Mc = mk(m.cr, m.cg, m.cb); kr = m.reflect;
+                }
+                col = add(mk(rk.x, rk.y, rk.z), muls(mulv(col, Mc), kr));
+            }
         }
         if (A.rgb32) { A.rgb32[3 * p] = col.x; A.rgb32[3 * p + 1] = col.y; A.rgb32[3 * p + 2] = col.z; }
         if (A.rgb8) { A.rgb8[3 * p] = quantise8(col.x); A.rgb8[3 * p + 1] = quantise8(col.y); A.rgb8[3 * p + 2] = quantise8(col.z); }
@@ -477,7 +521,8 @@ int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FramePar
     s.counters = counters;
     int sgrid = (s.n_pixels + BLOCK - 1) / BLOCK;
     if (sgrid > num_cus * 8) sgrid = num_cus * 8;
-    hipLaunchKernelGGL(k_shade_all, dim3(sgrid), dim3(BLOCK), 0, stream, s);
+    if (fp.max_depth + 1 <= 5) hipLaunchKernelGGL(k_shade_all<5>, dim3(sgrid), dim3(BLOCK), 0, stream, s);
+    else hipLaunchKernelGGL(k_shade_all<0>, dim3(sgrid), dim3(BLOCK), 0, stream, s);
     RT_HIP_CHECK(hipGetLastError(), err);
     return RT_OK;
 }
