@@ -530,66 +530,113 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     atomicMax(live_depth, depth[i] + 1);
 }
 
-// ---- 4-wide nodes.  A binary node at an even depth whose subtree is not collapsed becomes a wide node;
-// its children are its grandchildren (a child that is a leaf stays one child), so a ray that would
-// take two dependent node fetches takes one.  wide[i] = wide nodes in the subtree of binary node i
-// (bottom-up), pre4[i] = preorder position among the wide nodes (top-down).
+// ---- 4-wide nodes.  A wide node is rooted at a binary node; its children are found by opening, up to
+// twice, the inner child with the largest surface area (the one a ray is most likely to enter), so that big
+// boxes are split further and small ones stay whole.  WIDE_COLLAPSE 0 restores the fixed rule (every binary
+// node at an even depth is a wide root, its children are its grandchildren).  The choice is made once, at
+// build time, and kept in wkids: a refit moves boxes, and the tree must not change under it.
+// root[i] = 1 + wide depth if binary node i is a wide root, else 0; wkids[i] = its children (binary node ids,
+// >= n-1: a single triangle; -1: unused slot).  wide[i] = wide roots in the subtree of i (bottom-up),
+// pre4[i] = preorder position among the wide roots (top-down).
+#ifndef WIDE_COLLAPSE
+#define WIDE_COLLAPSE 1
+#endif
+
+__device__ __forceinline__ bool wide_is_leaf(int c, const int2 *range, int n, int leaf_max)
+{
+    if (c >= n - 1) return true;
+    const int2 rg = range[c];
+    return rg.y - rg.x + 1 <= leaf_max;
+}
+
+__device__ __forceinline__ float box_area(int c, const float4 *box_lo, const float4 *box_hi)
+{
+    const float4 l = box_lo[c], h = box_hi[c];
+    const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_wide_mark_level(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
+                                  const int *__restrict__ live, const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                                  int n, int leaf_max, int level, int *root, int4 *wkids)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || depth[i] != level || live[i] == 0 || root[i] == 0) return;
+    int who[4] = { children[i].x, children[i].y, -1, -1 };
+    int m = 2;
+#if WIDE_COLLAPSE
+    while (m < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int k = 0; k < m; k++) {
+            if (wide_is_leaf(who[k], range, n, leaf_max)) continue;
+            const float a = box_area(who[k], box_lo, box_hi);
+            if (a > best_area) { best_area = a; best = k; }
+        }
+        if (best < 0) break;
+        const int2 g = children[who[best]];
+        for (int k = m; k > best + 1; k--) who[k] = who[k - 1];     // keep the slot order of the binary tree
+        who[best] = g.x;
+        who[best + 1] = g.y;
+        m++;
+    }
+#else
+    {
+        int out[4], q = 0;
+        for (int k = 0; k < 2; k++) {
+            if (wide_is_leaf(who[k], range, n, leaf_max)) { out[q++] = who[k]; continue; }
+            const int2 g = children[who[k]];
+            out[q++] = g.x;
+            out[q++] = g.y;
+        }
+        m = q;
+        for (int k = 0; k < 4; k++) who[k] = k < m ? out[k] : -1;
+    }
+#endif
+    wkids[i] = make_int4(who[0], who[1], who[2], who[3]);
+    for (int k = 0; k < m; k++)
+        if (!wide_is_leaf(who[k], range, n, leaf_max)) root[who[k]] = root[i] + 1;
+}
+
 __global__ void k_wide_live_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int *__restrict__ live,
-                                  int n, int level, int *wide)
+                                  const int *__restrict__ root, int n, int level, int *wide)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1 || depth[i] != level) return;
     if (live[i] == 0) { wide[i] = 0; return; }
     const int2 c = children[i];
-    wide[i] = ((level & 1) == 0 ? 1 : 0) + (c.x < n - 1 ? wide[c.x] : 0) + (c.y < n - 1 ? wide[c.y] : 0);
+    wide[i] = (root[i] ? 1 : 0) + (c.x < n - 1 ? wide[c.x] : 0) + (c.y < n - 1 ? wide[c.y] : 0);
 }
 
 __global__ void k_wide_pre_level(const int2 *__restrict__ children, const int *__restrict__ depth, const int *__restrict__ live,
-                                 const int *__restrict__ wide, int n, int level, int *pre4)
+                                 const int *__restrict__ wide, const int *__restrict__ root, int n, int level, int *pre4)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1 || depth[i] != level || live[i] == 0) return;
     const int2 c = children[i];
-    const int first = pre4[i] + ((level & 1) == 0 ? 1 : 0);
+    const int first = pre4[i] + (root[i] ? 1 : 0);
     if (c.x < n - 1 && live[c.x]) pre4[c.x] = first;
     if (c.y < n - 1 && live[c.y]) pre4[c.y] = first + (c.x < n - 1 ? wide[c.x] : 0);
 }
 
 // The top of the wide tree (wide depths 0..WIDE_TOP_LEVELS-1) is numbered as a complete 4-ary tree
 // (root 0, children of slot s at 4s+1..4s+4) so that it sits at the start of the node array, where the
-// traversal kernel keeps a copy in LDS; every other wide node follows in preorder.
-__device__ __forceinline__ int wide_index(int i, const int *depth, const int *slot, const int *pre4)
+// traversal kernel can keep a copy in LDS; every other wide node follows in preorder.
+__device__ __forceinline__ int wide_index(int i, const int *root, const int *slot, const int *pre4)
 {
-    return depth[i] / 2 < WIDE_TOP_LEVELS ? slot[i] : WIDE_TOP_NODES + pre4[i];
+    return root[i] - 1 < WIDE_TOP_LEVELS ? slot[i] : WIDE_TOP_NODES + pre4[i];
 }
 
-// Children of wide node i in slot order: binary node ids (>= n-1: a single triangle), at most 4.
-__device__ __forceinline__ int wide_children(int i, const int2 *children, const int2 *range, int n, int leaf_max, int *who)
-{
-    int m = 0;
-    const int2 c = children[i];
-    const int cc[2] = { c.x, c.y };
-    for (int k = 0; k < 2; k++) {
-        bool leaf = cc[k] >= n - 1;
-        if (!leaf) { const int2 rg = range[cc[k]]; leaf = rg.y - rg.x + 1 <= leaf_max; }
-        if (leaf) { who[m++] = cc[k]; continue; }
-        const int2 g = children[cc[k]];                 // an inner child at an odd depth: take its children
-        who[m++] = g.x;
-        who[m++] = g.y;
-    }
-    return m;
-}
-
-__global__ void k_wide_slots(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
-                             const int *__restrict__ live, int n, int leaf_max, int wide_level, int *slot)
+__global__ void k_wide_slots(const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
+                             const int4 *__restrict__ wkids, int n, int leaf_max, int wide_level, int *slot)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || live[i] == 0 || depth[i] != 2 * wide_level) return;
-    int who[4];
-    const int m = wide_children(i, children, range, n, leaf_max, who);
+    if (i >= n - 1 || live[i] == 0 || root[i] != wide_level + 1) return;
+    const int4 w = wkids[i];
+    const int who[4] = { w.x, w.y, w.z, w.w };
     const int s = slot[i];
-    for (int k = 0; k < m; k++)
-        if (who[k] < n - 1 && live[who[k]]) slot[who[k]] = 4 * s + 1 + k;
+    for (int k = 0; k < 4; k++)
+        if (who[k] >= 0 && !wide_is_leaf(who[k], range, n, leaf_max)) slot[who[k]] = 4 * s + 1 + k;
 }
 
 // A box rounded OUTWARD onto the 15-bit lattice, one word per axis: (0x8000 | lo) | (0x8000 | hi) << 16.
@@ -605,44 +652,47 @@ __device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, c
     }
 }
 
-__global__ void k_emit_wide(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ depth,
-                            const int *__restrict__ live, int n, int leaf_max, const float4 *__restrict__ box_lo,
+__global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
+                            const int4 *__restrict__ wkids, int n, int leaf_max, const float4 *__restrict__ box_lo,
                             const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
                             const int *__restrict__ slot, BvhNode4 *wnodes, int *wide_depth)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || live[i] == 0 || (depth[i] & 1)) return;
+    if (i >= n - 1 || live[i] == 0 || root[i] == 0) return;
     const float4 rlo = box_lo[0], rhi = box_hi[0];
     const float gb[3] = { rlo.x, rlo.y, rlo.z };
     float gs[3] = { (rhi.x - rlo.x) * (1.0f / 32767.0f), (rhi.y - rlo.y) * (1.0f / 32767.0f), (rhi.z - rlo.z) * (1.0f / 32767.0f) };
     for (int k = 0; k < 3; k++)
         if (!(gs[k] > 0.0f)) gs[k] = 1e-30f;
     // children in slot order: binary node (or single-triangle) ids and their references
-    int who[4], ref[4];
-    const int m = wide_children(i, children, range, n, leaf_max, who);
-    for (int k = 0; k < m; k++) {
+    const int4 wk = wkids[i];
+    const int who[4] = { wk.x, wk.y, wk.z, wk.w };
+    int ref[4];
+    unsigned int w[12];
+    for (int k = 0; k < 4; k++) {
         const int c = who[k];
+        if (c < 0) {
+            w[3 * k] = w[3 * k + 1] = w[3 * k + 2] = 0x8000ffffu;     // lo = 32767 > hi = 0: never entered
+            ref[k] = 0x7fffffff;
+            continue;
+        }
         if (c >= n - 1) {
             const int j = c - (n - 1);
             ref[k] = ~(((leafpos ? leafpos[j] : j) << 3) | 0);
         } else {
             const int2 rg = range[c];
             const int cnt = rg.y - rg.x + 1;
-            ref[k] = cnt <= leaf_max ? ~((rg.x << 3) | (cnt - 1)) : wide_index(c, depth, slot, pre4);
+            ref[k] = cnt <= leaf_max ? ~((rg.x << 3) | (cnt - 1)) : wide_index(c, root, slot, pre4);
         }
-    }
-    unsigned int w[12];
-    for (int k = 0; k < 4; k++) {
-        if (k < m) lattice_box(box_lo[who[k]], box_hi[who[k]], gb, gs, w + 3 * k);
-        else { w[3 * k] = w[3 * k + 1] = w[3 * k + 2] = 0x8000ffffu; ref[k] = 0x7fffffff; }   // lo = 32767 > hi = 0: never entered
+        lattice_box(box_lo[c], box_hi[c], gb, gs, w + 3 * k);
     }
     BvhNode4 nd;
     nd.a = make_uint4(w[0], w[1], w[2], w[3]);
     nd.b = make_uint4(w[4], w[5], w[6], w[7]);
     nd.c = make_uint4(w[8], w[9], w[10], w[11]);
     nd.d = make_uint4((unsigned)ref[0], (unsigned)ref[1], (unsigned)ref[2], (unsigned)ref[3]);
-    wnodes[wide_index(i, depth, slot, pre4)] = nd;
-    atomicMax(wide_depth, depth[i] / 2 + 1);
+    wnodes[wide_index(i, root, slot, pre4)] = nd;
+    atomicMax(wide_depth, root[i]);
 }
 
 __global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals,
@@ -683,12 +733,13 @@ struct LbvhTopology {
     unsigned int *bounds = nullptr, *vals = nullptr;
     int2 *children = nullptr, *range = nullptr;
     int *parent = nullptr, *depth = nullptr, *scalars = nullptr, *leafpos = nullptr, *order = nullptr;
-    int *live = nullptr, *pre = nullptr, *pre4 = nullptr, *slot = nullptr;
+    int *live = nullptr, *pre = nullptr, *pre4 = nullptr, *slot = nullptr, *root = nullptr;
+    int4 *wkids = nullptr;
     float4 *box_lo = nullptr, *box_hi = nullptr;
     QuantGrid *grid = nullptr;
     ~LbvhTopology()
     {
-        void *ptrs[] = { bounds, vals, children, range, parent, depth, scalars, leafpos, order, live, pre, pre4, slot, box_lo, box_hi, grid };
+        void *ptrs[] = { bounds, vals, children, range, parent, depth, scalars, leafpos, order, live, pre, pre4, slot, root, wkids, box_lo, box_hi, grid };
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
     }
@@ -855,30 +906,32 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
                        leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes, out->qnodes,
                        grid.p, scalars.p + 1);
-    DevBuf<int> wide, pre4;
-    if (wide.alloc(n) != hipSuccess || pre4.alloc(n) != hipSuccess) {
+    DevBuf<int> wide, pre4, root, slot;
+    DevBuf<int4> wkids;
+    if (wide.alloc(n) != hipSuccess || pre4.alloc(n) != hipSuccess || root.alloc(n) != hipSuccess || slot.alloc(n) != hipSuccess ||
+        wkids.alloc(n) != hipSuccess) {
         if (err) *err = "wide node allocation failed";
         lbvh_free(out);
         return RT_E_NOMEM;
     }
     RT_HIP_CHECK(hipMemsetAsync(pre4.p, 0, sizeof(int) * (size_t)n, stream), err);
-    for (int level = max_depth; level >= 0; level--)
-        hipLaunchKernelGGL(k_wide_live_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, n, level,
-                           wide.p);
-    for (int level = 0; level <= max_depth; level++)
-        hipLaunchKernelGGL(k_wide_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, wide.p, n,
-                           level, pre4.p);
-    DevBuf<int> slot;
-    if (slot.alloc(n) != hipSuccess) {
-        if (err) *err = "wide node allocation failed";
-        lbvh_free(out);
-        return RT_E_NOMEM;
-    }
     RT_HIP_CHECK(hipMemsetAsync(slot.p, 0, sizeof(int) * (size_t)n, stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(root.p, 0, sizeof(int) * (size_t)n, stream), err);
+    const int one = 1;
+    RT_HIP_CHECK(hipMemcpyAsync(root.p, &one, sizeof(int), hipMemcpyHostToDevice, stream), err);     // binary node 0 is the wide root
+    for (int level = 0; level <= max_depth; level++)
+        hipLaunchKernelGGL(k_wide_mark_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p,
+                           box_lo.p, box_hi.p, n, leaf_max, level, root.p, wkids.p);
+    for (int level = max_depth; level >= 0; level--)
+        hipLaunchKernelGGL(k_wide_live_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, root.p, n,
+                           level, wide.p);
+    for (int level = 0; level <= max_depth; level++)
+        hipLaunchKernelGGL(k_wide_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, live.p, wide.p,
+                           root.p, n, level, pre4.p);
     for (int wl = 0; wl + 1 < WIDE_TOP_LEVELS; wl++)
-        hipLaunchKernelGGL(k_wide_slots, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p, n,
-                           leaf_max, wl, slot.p);
-    hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, depth.p, live.p, n, leaf_max,
+        hipLaunchKernelGGL(k_wide_slots, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, range.p, live.p, root.p, wkids.p, n, leaf_max,
+                           wl, slot.p);
+    hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, range.p, live.p, root.p, wkids.p, n, leaf_max,
                        box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, slot.p, out->wnodes, scalars.p + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
                        out->bvh_tri);
@@ -905,7 +958,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
         t->children = children.release(); t->range = range.release(); t->parent = parent.release();
         t->depth = depth.release(); t->scalars = scalars.release();
         t->leafpos = leafpos.release(); t->order = order.release();
-        t->live = live.release(); t->pre = pre.release(); t->pre4 = pre4.release(); t->slot = slot.release();
+        t->live = live.release(); t->pre = pre.release(); t->pre4 = pre4.release(); t->slot = slot.release(); t->root = root.release(); t->wkids = wkids.release();
         t->box_lo = box_lo.release(); t->box_hi = box_hi.release(); t->grid = grid.release();
     }
     out->topo = t;
@@ -935,8 +988,8 @@ int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out,
         hipLaunchKernelGGL(k_refit_level, dim3(GI), dim3(B), 0, stream, t->children, t->depth, n - 1, level, t->box_lo, t->box_hi);
     hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->parent, t->depth, n, out->leaf_max,
                        t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, out->qnodes, t->grid, t->scalars + 1);
-    hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->depth, t->live, n, out->leaf_max,
-                       t->box_lo, t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
+    hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->range, t->live, t->root, t->wkids, n, out->leaf_max, t->box_lo,
+                       t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, t->ploc ? t->order : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
