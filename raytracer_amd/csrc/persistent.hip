@@ -410,6 +410,9 @@ __device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p,
     return out;
 }
 
+#ifndef SHADE_REG9
+#define SHADE_REG9 1
+#endif
 // REG_LEVELS > 0: the frame has at most that many levels and a pixel's local colours stay in registers
 // between the walk down its chain and the fold back up; 0: any depth, through the records plane.
 template <int REG_LEVELS>
@@ -522,6 +525,7 @@ int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FramePar
     int sgrid = (s.n_pixels + BLOCK - 1) / BLOCK;
     if (sgrid > num_cus * 8) sgrid = num_cus * 8;
     if (fp.max_depth + 1 <= 5) hipLaunchKernelGGL(k_shade_all<5>, dim3(sgrid), dim3(BLOCK), 0, stream, s);
+    else if (SHADE_REG9 && fp.max_depth + 1 <= 9) hipLaunchKernelGGL(k_shade_all<9>, dim3(sgrid), dim3(BLOCK), 0, stream, s);
     else hipLaunchKernelGGL(k_shade_all<0>, dim3(sgrid), dim3(BLOCK), 0, stream, s);
     RT_HIP_CHECK(hipGetLastError(), err);
     return RT_OK;
