@@ -44,6 +44,7 @@ struct rt_ctx {
     int opt_graph = 1;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<unsigned char> graph_key;
+    std::vector<unsigned char> last_key;     // the previous frame's key, captured or not
     unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
     // last frame
     bool frame_valid = false;
@@ -91,6 +92,7 @@ void drop_graph(rt_ctx *c)
     c->graph_exec = nullptr;
     c->graph_key.clear();
 }
+
 
 void free_triangles(rt_ctx *c)
 {
@@ -352,10 +354,15 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         memcpy(key.ws, wsp, sizeof wsp);
         key.version = c->state_version;
         const bool same = c->graph_exec && c->graph_key.size() == sizeof key && memcmp(c->graph_key.data(), &key, sizeof key) == 0;
+        // A frame that differs from the last one (moving camera, moving geometry) is launched directly; the
+        // capture is made when the same frame is asked for a second time in a row, so that a changing frame
+        // never pays for a capture it will not replay.
+        const bool repeat = c->last_key.size() == sizeof key && memcmp(c->last_key.data(), &key, sizeof key) == 0;
+        c->last_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
         if (!same) {
             drop_graph(c);
             hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (repeat && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, c->stream, &launches, &err);
                 const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
                 if (rc == RT_OK && ee == hipSuccess && graph &&

@@ -228,7 +228,7 @@ def test_band_partition_of_an_lbvh_scene_matches_the_whole_frame():
 
 def test_graph_replay_of_an_unchanged_frame_and_recapture_after_a_change():
     """With timing off an unchanged frame replays a captured hipGraph: same bytes as the direct launches,
-    also after the camera, the depth and the scene change (each forces a new capture)."""
+    also after the camera, the depth and the scene change (each is launched directly once, captured on its repeat)."""
     import torch
     spec = atrium_spec(detail=0.02)
     W, H = 160, 120
@@ -239,7 +239,7 @@ def test_graph_replay_of_an_unchanged_frame_and_recapture_after_a_change():
         out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
         ids = torch.zeros((H, W), dtype=torch.int32, device="cuda")
         res = []
-        for _ in range(3):                                   # first call captures, the next two replay
+        for _ in range(4):                                   # direct launches, then the capture, then two replays
             out.zero_(); ids.zero_()
             ctx.render_rows_device(W, H, rs, depth, out.data_ptr(), ids.data_ptr(), None, None, stream)
             torch.cuda.synchronize()
