@@ -149,6 +149,12 @@ int rt_set_triangle_materials(rt_ctx *ctx, const rt_material *mats, int n_mats,
  * meshes (rt_set_mesh / rt_set_triangles) drop the normals; rt_update_* keep them. */
 int rt_set_triangle_normals(rt_ctx *ctx, const float *corner_normals, int n_tris);
 
+/* Texture coordinates from the `vt` statements the reference parses and never uses (objloader.cpp:48-55;
+ * the reference has no textures): corner_uv = n_tris x (at v1, at v2, at v3) x (u,v).  Nothing in the image
+ * reads them; their one consumer is the uv plane of rt_render_frame_planes.  NULL drops them; a replaced mesh
+ * drops them, rt_update_* keep them. */
+int rt_set_triangle_texcoords(rt_ctx *ctx, const float *corner_uv, int n_tris);
+
 /* Moving geometry for the per-tick re-render (draw(dt), main.cpp:284-287, glwt.mm:68-82; the reference
  * itself redraws one static frame): new positions for the triangles already loaded, same count and
  * order.  Materials and the hierarchy's topology stay; the Triangle constructor (main.cpp:104-107) runs
@@ -180,6 +186,8 @@ typedef struct rt_frame_planes {
     float *rgb32;
     float *hit_t;
     float *normal;
+    float *uv;          /* 2 floats per pixel: the texture coordinate at the camera ray's hit, interpolated with Triangle::Raycast's
+                           u, v (main.cpp:119, 124); (0,0) on a miss, on a sphere or plane, or without rt_set_triangle_texcoords */
 } rt_frame_planes;
 int rt_render_frame_planes(rt_ctx *ctx, int W, int H, int y0, int y1, int max_depth, const rt_frame_planes *out);
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_option", "rt_set_analytic",
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
-    "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals",
+    "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals", "rt_set_triangle_texcoords",
 )
 
 
@@ -68,7 +68,7 @@ class RowSet(C.Structure):
 
 
 class FramePlanes(C.Structure):
-    _fields_ = [("rgb8", C.c_void_p), ("hit_id", C.c_void_p), ("rgb32", C.c_void_p), ("hit_t", C.c_void_p), ("normal", C.c_void_p)]
+    _fields_ = [("rgb8", C.c_void_p), ("hit_id", C.c_void_p), ("rgb32", C.c_void_p), ("hit_t", C.c_void_p), ("normal", C.c_void_p), ("uv", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -164,6 +164,7 @@ def load_library():
     L.rt_set_triangles.argtypes = [vp, vp, i32, C.POINTER(Material)]
     L.rt_set_triangle_materials.argtypes = [vp, C.POINTER(Material), i32, vp, i32]
     L.rt_set_triangle_normals.argtypes = [vp, vp, i32]
+    L.rt_set_triangle_texcoords.argtypes = [vp, vp, i32]
     L.rt_update_triangles.argtypes = [vp, vp, i32]
     L.rt_update_mesh_vertices.argtypes = [vp, vp, i32]
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
@@ -242,6 +243,14 @@ class Context:
         v = np.ascontiguousarray(corner_normals, dtype=np.float32).reshape(-1, 9)
         self._check(self.L.rt_set_triangle_normals(self._h, v.ctypes.data, v.shape[0]))
 
+    def set_triangle_texcoords(self, corner_uv):
+        """rt_set_triangle_texcoords: (n_tris, 3, 2) texture coordinates at v1, v2, v3; None drops them."""
+        if corner_uv is None:
+            self._check(self.L.rt_set_triangle_texcoords(self._h, None, 0))
+            return
+        v = np.ascontiguousarray(corner_uv, dtype=np.float32).reshape(-1, 6)
+        self._check(self.L.rt_set_triangle_texcoords(self._h, v.ctypes.data, v.shape[0]))
+
     def update_triangles(self, tri_verts):
         """rt_update_triangles: moved vertices for the loaded triangles (same count and order)."""
         v = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
@@ -272,8 +281,8 @@ class Context:
         rows = max(y1 - y0, 0)
         out = dict(rgb8=np.zeros((rows, W, 3), np.uint8), hit_id=np.full((rows, W), -2, np.int32),
                    rgb32=np.zeros((rows, W, 3), np.float32), hit_t=np.zeros((rows, W), np.float32),
-                   normal=np.zeros((rows, W, 3), np.float32))
-        fp = FramePlanes(*[out[k].ctypes.data if out[k].size else None for k in ("rgb8", "hit_id", "rgb32", "hit_t", "normal")])
+                   normal=np.zeros((rows, W, 3), np.float32), uv=np.zeros((rows, W, 2), np.float32))
+        fp = FramePlanes(*[out[k].ctypes.data if out[k].size else None for k in ("rgb8", "hit_id", "rgb32", "hit_t", "normal", "uv")])
         self._check(self.L.rt_render_frame_planes(self._h, W, H, y0, y1, max_depth, C.byref(fp)))
         return out
 

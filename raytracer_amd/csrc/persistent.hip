@@ -342,7 +342,7 @@ struct ShadeAllArgs {
     const unsigned int *occ;          // [level][chunk][pixel], 32 lights per chunk
     int n_chunks;
     float4 *records;                  // [level][pixel] scratch: (local colour, hit id bits)
-    uint8_t *rgb8; int32_t *hit_id; float *rgb32; float *hit_t; float *normal;
+    uint8_t *rgb8; int32_t *hit_id; float *rgb32; float *hit_t; float *normal; float *uv;
     FrameCounters *counters;
 };
 
@@ -370,6 +370,10 @@ __device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p,
         id0 = id;
         if (A.hit_t) A.hit_t[p] = t;
         if (A.normal && id < 0) { A.normal[3 * p] = 0.f; A.normal[3 * p + 1] = 0.f; A.normal[3 * p + 2] = 0.f; }
+        if (A.uv) {
+            const float2 tc = id >= 0 ? hit_uv(sc, id, o, d) : make_float2(0.f, 0.f);
+            A.uv[2 * p] = tc.x; A.uv[2 * p + 1] = tc.y;
+        }
     }
     F3 col = mk(0.f, 0.f, 0.f);                                                   // main.cpp:159-160
     out.spawn = false;
@@ -521,6 +525,7 @@ int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FramePar
     s.hits = hits; s.occ = occ; s.n_chunks = n_chunks; s.records = records;
     s.rgb8 = (uint8_t *)d_rgb8; s.hit_id = (int32_t *)d_hit_id; s.rgb32 = (float *)d_rgb32; s.hit_t = (float *)d_hit_t;
     s.normal = fp.d_normal;
+    s.uv = fp.d_uv;
     s.counters = counters;
     int sgrid = (s.n_pixels + BLOCK - 1) / BLOCK;
     if (sgrid > num_cus * 8) sgrid = num_cus * 8;

@@ -169,6 +169,25 @@ __device__ __forceinline__ F3 smooth_normal(const DevScene &sc, int tri, F3 o, F
     return normalize(add(add(muls(n1, w), muls(n2, u)), muls(n3, v)));
 }
 
+// Texture coordinate of a triangle hit (the reference parses `vt` and never uses it, objloader.cpp:48-55):
+// the corner coordinates weighted by the barycentrics of Triangle::Raycast (main.cpp:110-124).  (0, 0) for
+// a miss, an analytic primitive, or when no coordinates are loaded.
+__device__ __forceinline__ float2 hit_uv(const DevScene &sc, int id, F3 o, F3 d)
+{
+    if (!sc.tri_vt || id < sc.n_analytic) return make_float2(0.f, 0.f);
+    const int tri = id - sc.n_analytic;
+    const F3 v1 = f3(sc.tri_mt[3 * (size_t)tri]), e1 = f3(sc.tri_mt[3 * (size_t)tri + 1]), e2 = f3(sc.tri_mt[3 * (size_t)tri + 2]);
+    const F3 P = cross(d, e2);                          // main.cpp:111
+    const float invdet = 1.0f / dot(e1, P);             // main.cpp:112, 116
+    const F3 T = sub(o, v1);                            // main.cpp:118
+    const float u = dot(T, P) * invdet;                 // main.cpp:119
+    const F3 Q = cross(T, e1);                          // main.cpp:123
+    const float v = dot(d, Q) * invdet;                 // main.cpp:124
+    const float w = 1.0f - u - v;
+    const float2 t1 = sc.tri_vt[3 * (size_t)tri], t2 = sc.tri_vt[3 * (size_t)tri + 1], t3 = sc.tri_vt[3 * (size_t)tri + 2];
+    return make_float2(t1.x * w + t2.x * u + t3.x * v, t1.y * w + t2.y * u + t3.y * v);
+}
+
 // Surface data of a hit primitive: normal (main.cpp:70-73, 94-97, 131-134) and material.  (o, d) is the
 // ray that hit; only the opt-in shading normals read it.
 struct Surface { F3 N, Mc; float kr, kd, ks; bool emissive; };

@@ -74,6 +74,7 @@ struct DevScene {
     const float4 *tri_mt;          // [n_tris*3] original order: (v1,·) (e1,·) (e2,·)
     const float4 *tri_n;           // [n_tris] (N.xyz, material index as int bits)
     const float4 *tri_vn;          // [n_tris*3] shading normals at v1, v2, v3, or null: geometric normals (the reference)
+    const float2 *tri_vt;          // [n_tris*3] texture coordinates at v1, v2, v3, or null (only the uv plane reads them)
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
     const BvhNodeQ *qnodes;        // same tree, quantised boxes
@@ -138,6 +139,7 @@ struct FrameParams {
     int wide_depth;                // depth of the 4-wide tree
     int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages, 3 single traversal launch
     float *d_normal;               // optional device plane: the primary hit's normal, 3 floats per pixel (0 on a miss)
+    float *d_uv;                   // optional device plane: the primary hit's texture coordinate, 2 floats per pixel
 };
 
 struct FrameWorkspace {
@@ -164,7 +166,7 @@ struct FrameWorkspace {
     float4 *ls_o = nullptr, *ls_d = nullptr;   // [waves][ls_entries] private ray stacks
     size_t p_cap = 0, ls_cap = 0;  // elements allocated in p_hits / p_occ and in ls_o / ls_d
     // staging outputs for the host-buffer entry point
-    uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr; float *out_normal = nullptr;
+    uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr; float *out_normal = nullptr; float *out_uv = nullptr;
     size_t out_cap = 0;
     std::vector<hipEvent_t> events;        // frame start, after each traversal stage, after the final fold
     int n_events = 0;                      // events recorded by the last frame

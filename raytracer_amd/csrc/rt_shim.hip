@@ -32,6 +32,7 @@ struct rt_ctx {
     int n_tris = 0;
     int32_t *d_indices = nullptr;   // kept from rt_set_mesh for rt_update_mesh_vertices
     float4 *d_tri_vn = nullptr;     // opt-in shading normals, 3 per triangle (rt_set_triangle_normals)
+    float2 *d_tri_vt = nullptr;     // texture coordinates, 3 per triangle (rt_set_triangle_texcoords)
     int n_mesh_verts = 0;
     DevMaterial *d_mats = nullptr;
     int n_mats = 0;
@@ -103,6 +104,8 @@ void free_triangles(rt_ctx *c)
     if (c->d_indices) (void)hipFree(c->d_indices);
     if (c->d_tri_vn) (void)hipFree(c->d_tri_vn);
     c->d_tri_vn = nullptr;
+    if (c->d_tri_vt) (void)hipFree(c->d_tri_vt);
+    c->d_tri_vt = nullptr;
     c->d_tri_mt = c->d_tri_n = nullptr;
     c->d_mats = nullptr;
     c->d_indices = nullptr;
@@ -115,7 +118,7 @@ void free_triangles(rt_ctx *c)
 void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
-                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
                      ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -242,14 +245,15 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         }
     }
     if (host_outputs && pixels > ws.out_cap) {
-        void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal };
+        void *old[] = { ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv };
         for (void *p : old)
             if (p) (void)hipFree(p);
-        ws.out_rgb8 = nullptr; ws.out_id = nullptr; ws.out_rgb32 = nullptr; ws.out_normal = nullptr; ws.out_cap = 0;
+        ws.out_rgb8 = nullptr; ws.out_id = nullptr; ws.out_rgb32 = nullptr; ws.out_normal = nullptr; ws.out_uv = nullptr; ws.out_cap = 0;
         hipError_t e = hipMalloc((void **)&ws.out_rgb8, 3 * pixels);
         if (e == hipSuccess) e = hipMalloc((void **)&ws.out_id, sizeof(int32_t) * pixels);
         if (e == hipSuccess) e = hipMalloc((void **)&ws.out_rgb32, sizeof(float) * 3 * pixels);
         if (e == hipSuccess) e = hipMalloc((void **)&ws.out_normal, sizeof(float) * 3 * pixels);
+        if (e == hipSuccess) e = hipMalloc((void **)&ws.out_uv, sizeof(float) * 2 * pixels);
         if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("output staging: ") + hipGetErrorString(e));
         ws.out_cap = pixels;
     }
@@ -318,7 +322,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
 
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
-    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.mats = c->d_mats;
+    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
     sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
 
@@ -329,11 +333,13 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     fp.wide_depth = accel ? c->bvh.wide_depth : 0;
     fp.pipeline = c->opt_pipeline;
     fp.d_normal = nullptr;
+    fp.d_uv = nullptr;
     if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
     if (host_aov) {
         if (!c->ws.out_normal || c->ws.out_cap < pixels) return fail(RT_E_STATE, "plane staging missing");
         d_hit_t = c->ws.hit_t;
         fp.d_normal = c->ws.out_normal;
+        fp.d_uv = c->ws.out_uv;
     }
     std::string err;
     int launches = 0;
@@ -719,6 +725,31 @@ int rt_set_triangle_normals(rt_ctx *c, const float *corner_normals, int n_tris)
     return RT_OK;
 }
 
+int rt_set_triangle_texcoords(rt_ctx *c, const float *corner_uv, int n_tris)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (!corner_uv) {
+        if (c->d_tri_vt) (void)hipFree(c->d_tri_vt);
+        c->d_tri_vt = nullptr;
+        c->state_version++;
+        return RT_OK;
+    }
+    if (n_tris != c->n_tris || c->n_tris == 0) return fail(RT_E_STATE, "triangle count does not match the loaded mesh");
+    float2 *d = nullptr;
+    const size_t bytes = sizeof(float2) * 3 * (size_t)n_tris;
+    if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(texcoords)");
+    if (hipMemcpy(d, corner_uv, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(RT_E_DEVICE, "upload texcoords");
+    }
+    if (c->d_tri_vt) (void)hipFree(c->d_tri_vt);
+    c->d_tri_vt = d;
+    c->state_version++;
+    return RT_OK;
+}
+
 int rt_set_camera(rt_ctx *c, const rt_camera *cam)
 {
     if (!c) return fail(RT_E_INVALID, "null context");
@@ -768,6 +799,7 @@ int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_dept
     pull(out->rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels);
     pull(out->hit_t, c->ws.hit_t, sizeof(float) * pixels);
     pull(out->normal, c->ws.out_normal, sizeof(float) * 3 * pixels);
+    pull(out->uv, c->ws.out_uv, sizeof(float) * 2 * pixels);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
     return RT_OK;

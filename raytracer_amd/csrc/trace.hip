@@ -147,6 +147,7 @@ struct BounceArgs {
     float4 *records;                 // [level][pixel]
     float *hit_t;                    // level 0 only, may be null
     float *normal;                   // level 0 only, may be null
+    float *uv;                       // level 0 only, may be null
     const float4 *q_in_o, *q_in_d;   // level > 0
     float4 *q_out_o, *q_out_d;
     const unsigned int *counts_in;    // level > 0: rays in each 64-slot batch of the input queue
@@ -282,6 +283,10 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             if (PRIMARY && A.normal) {
                 const F3 Nn = hit ? N : mk(0.f, 0.f, 0.f);
                 A.normal[3 * (size_t)pixel] = Nn.x; A.normal[3 * (size_t)pixel + 1] = Nn.y; A.normal[3 * (size_t)pixel + 2] = Nn.z;
+            }
+            if (PRIMARY && A.uv) {
+                const float2 tc = hit ? hit_uv(sc, best_id, o, d) : make_float2(0.f, 0.f);
+                A.uv[2 * (size_t)pixel] = tc.x; A.uv[2 * (size_t)pixel + 1] = tc.y;
             }
         }
         const bool spawn = lit && kr > 0.0f && more;
@@ -460,6 +465,7 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     a.records = ws.records;
     a.hit_t = (float *)d_hit_t;
     a.normal = fp.d_normal;
+    a.uv = fp.d_uv;
     a.counters = ws.counters;
     a.stack_cap = fp.stack_depth;
 

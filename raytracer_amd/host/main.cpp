@@ -38,7 +38,7 @@ struct Config {
 } cfg;
 
 color *image = nullptr;                                      // main.cpp:16
-std::vector<float> image_rgb32, image_t, image_normal;
+std::vector<float> image_rgb32, image_t, image_normal, image_uv;
 std::vector<int32_t> image_ids;
 rt_ctx *ctx = nullptr;
 int exit_code = 0;
@@ -47,6 +47,7 @@ double total_rays = 0.0, total_device_ms = 0.0, total_refit_ms = 0.0, clock_s = 
 std::vector<float> rest_verts, moved_verts;                  // mesh vertices as loaded / as animated (--wobble)
 rt_camera base_cam;
 bool render_once(bool report);
+bool have_uv = false;
 
 rt_material material(float reflect, float diffuse, float spec, float r, float g, float b)
 {
@@ -105,6 +106,13 @@ bool LoadModel(const char *model)
         if (!check(rt_set_triangle_materials(ctx, mats.data(), (int)mats.size(), m.tri_material.data(), (int)m.tri_material.size()),
                    "rt_set_triangle_materials"))
             return false;
+        if (!cfg.exr.empty()) {                                  // the EXR's u, v channels
+            std::vector<float> vt;
+            if (CornerTexcoords(m, vt) > 0) {
+                if (!check(rt_set_triangle_texcoords(ctx, vt.data(), (int)m.tri_material.size()), "rt_set_triangle_texcoords")) return false;
+                have_uv = true;
+            }
+        }
         if (cfg.smooth) {
             std::vector<float> vn;
             const int with = CornerNormals(m, vn);
@@ -134,7 +142,8 @@ bool LoadModel(const char *model)
 bool render_once(bool report)
 {
     if (!image_t.empty()) {                        // EXR wanted: colour plus the t and normal planes
-        rt_frame_planes planes = { (uint8_t *)image, image_ids.data(), image_rgb32.data(), image_t.data(), image_normal.data() };
+        rt_frame_planes planes = { (uint8_t *)image, image_ids.data(), image_rgb32.data(), image_t.data(), image_normal.data(),
+                                   image_uv.empty() ? nullptr : image_uv.data() };
         if (!check(rt_render_frame_planes(ctx, cfg.imageWidth, cfg.imageHeight, 0, cfg.imageHeight, cfg.maxDepth, &planes),
                    "rt_render_frame_planes"))
             return false;
@@ -190,14 +199,15 @@ void setup()
     image = new color[n];                                                       // main.cpp:259
     if (!cfg.pfm.empty() || !cfg.exr.empty()) image_rgb32.resize(3 * n);
     if (!cfg.ids.empty() || !cfg.exr.empty()) image_ids.resize(n);
-    if (!cfg.exr.empty()) { image_t.resize(n); image_normal.resize(3 * n); }
+    if (!cfg.exr.empty()) { image_t.resize(n); image_normal.resize(3 * n); if (have_uv) image_uv.resize(2 * n); }
 
     printf("Rendering...\n");                                                   // main.cpp:261
     if (!render_once(true)) return;
 
     texturerenderer_set_output(cfg.out.empty() ? nullptr : cfg.out.c_str(), cfg.raw_order);
     if (!cfg.pfm.empty()) texturerenderer_set_float_output(cfg.pfm.c_str(), image_rgb32.data());
-    if (!cfg.exr.empty()) texturerenderer_set_exr_output(cfg.exr.c_str(), image_rgb32.data(), image_ids.data(), image_t.data(), image_normal.data());
+    if (!cfg.exr.empty()) texturerenderer_set_exr_output(cfg.exr.c_str(), image_rgb32.data(), image_ids.data(), image_t.data(), image_normal.data(),
+                                                         image_uv.empty() ? nullptr : image_uv.data());
     texturerenderer_displaytexture(image, cfg.imageWidth, cfg.imageHeight);    // main.cpp:281
     if (!cfg.ids.empty()) {
         if (FILE *f = fopen(cfg.ids.c_str(), "wb")) {

@@ -293,3 +293,20 @@ int CornerNormals(const ObjModel &m, std::vector<float> &out)
     }
     return with;
 }
+
+int CornerTexcoords(const ObjModel &m, std::vector<float> &out)
+{
+    const size_t n_tris = m.indices.size() / 3;
+    out.assign(6 * n_tris, 0.0f);
+    int with = 0;
+    for (size_t t = 0; t < n_tris; t++) {
+        const int ix[3] = { m.texcoord_indices[3 * t], m.texcoord_indices[3 * t + 1], m.texcoord_indices[3 * t + 2] };
+        if (ix[0] < 0 || ix[1] < 0 || ix[2] < 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const vec2 &c = m.texcoords[(size_t)ix[k]];
+            out[6 * t + 2 * k] = c.x; out[6 * t + 2 * k + 1] = c.y;
+        }
+        with++;
+    }
+    return with;
+}

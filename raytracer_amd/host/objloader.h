@@ -53,3 +53,6 @@ bool LoadModelEx(const char *objFile, ObjModel &out);
 // of rt_set_triangle_normals: 9 floats per triangle; a triangle with a corner that names no normal
 // gets nine zeros (= keep the geometric normal).  Returns how many triangles carry normals.
 int CornerNormals(const ObjModel &m, std::vector<float> &out);
+// The same for the `vt` coordinates (objloader.cpp:48-55), 6 floats per triangle, in the layout of
+// rt_set_triangle_texcoords; a triangle with a corner that names none gets zeros.
+int CornerTexcoords(const ObjModel &m, std::vector<float> &out);

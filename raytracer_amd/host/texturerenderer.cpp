@@ -9,7 +9,7 @@
 
 namespace {
 std::string g_ppm, g_pfm, g_exr;
-const float *g_exr_rgb = nullptr, *g_exr_t = nullptr, *g_exr_n = nullptr;
+const float *g_exr_rgb = nullptr, *g_exr_t = nullptr, *g_exr_n = nullptr, *g_exr_uv = nullptr;
 const int *g_exr_ids = nullptr;
 bool g_raw = false;
 const color *g_pixels = nullptr;
@@ -32,8 +32,10 @@ void texturerenderer_set_float_output(const char *pfm_path, const float *rgb32)
     g_rgb32 = rgb32;
 }
 
-void texturerenderer_set_exr_output(const char *exr_path, const float *rgb32, const int *ids, const float *hit_t, const float *normal)
+void texturerenderer_set_exr_output(const char *exr_path, const float *rgb32, const int *ids, const float *hit_t, const float *normal,
+                                    const float *uv)
 {
+    g_exr_uv = uv;
     g_exr = exr_path ? exr_path : "";
     g_exr_rgb = rgb32;
     g_exr_ids = ids;
@@ -52,9 +54,10 @@ void attr(std::vector<unsigned char> &b, const char *name, const char *type, con
     put_str(b, name); put_str(b, type); put_i32(b, n); put(b, val, (size_t)n);
 }
 
-bool write_exr(const char *path, int w, int h, const float *rgb32, const int *ids, const float *hit_t, const float *normal)
+bool write_exr(const char *path, int w, int h, const float *rgb32, const int *ids, const float *hit_t, const float *normal,
+               const float *uv)
 {
-    // channels in alphabetical order (upper case sorts first): B G [N.x N.y N.z] R [Z] [id]
+    // channels in alphabetical order (upper case sorts first): B G [N.x N.y N.z] R [Z] [id] [u v]
     struct Chan { const char *name; int type; const float *src; int stride, comp; const int *isrc; };
     std::vector<Chan> chans;
     chans.push_back({ "B", 2, rgb32, 3, 2, nullptr });
@@ -67,6 +70,10 @@ bool write_exr(const char *path, int w, int h, const float *rgb32, const int *id
     chans.push_back({ "R", 2, rgb32, 3, 0, nullptr });
     if (hit_t) chans.push_back({ "Z", 2, hit_t, 1, 0, nullptr });
     if (ids) chans.push_back({ "id", 0, nullptr, 1, 0, ids });
+    if (uv) {
+        chans.push_back({ "u", 2, uv, 2, 0, nullptr });
+        chans.push_back({ "v", 2, uv, 2, 1, nullptr });
+    }
 
     std::vector<unsigned char> hd;
     const unsigned char magic[8] = { 0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0 };
@@ -154,6 +161,6 @@ void texturerenderer_draw()
         }
     }
     if (!g_exr.empty() && g_exr_rgb) {
-        if (!write_exr(g_exr.c_str(), g_w, g_h, g_exr_rgb, g_exr_ids, g_exr_t, g_exr_n)) fprintf(stderr, "cannot write %s\n", g_exr.c_str());
+        if (!write_exr(g_exr.c_str(), g_w, g_h, g_exr_rgb, g_exr_ids, g_exr_t, g_exr_n, g_exr_uv)) fprintf(stderr, "cannot write %s\n", g_exr.c_str());
     }
 }

@@ -18,6 +18,6 @@ void texturerenderer_set_output(const char *ppm_path, bool raw_order);
 void texturerenderer_set_float_output(const char *pfm_path, const float *rgb32);
 // Optional OpenEXR file (scanline, uncompressed): float channels B, G, R from rgb32 and, for every plane
 // that is not NULL, N.x N.y N.z (primary-hit normal), Z (primary-hit t) and a UINT channel "id" holding
-// hit id + 1 (0 = no hit).  Top row first, as EXR expects.
+// hit id + 1 (0 = no hit), and u v (the hit's texture coordinate).  Top row first, as EXR expects.
 void texturerenderer_set_exr_output(const char *exr_path, const float *rgb32, const int *ids, const float *hit_t = nullptr,
-                                    const float *normal = nullptr);
+                                    const float *normal = nullptr, const float *uv = nullptr);

@@ -488,6 +488,48 @@ def test_frame_planes_report_the_shading_normal_when_set():
     assert len(np.unique(np.round(n, 4), axis=0)) > 0.5 * ball.sum()
 
 
+# ------------------------------------------------------------------ texture coordinates (the uv plane)
+def _affine_uv(p):
+    """A texture coordinate that is an affine function of position: barycentric interpolation reproduces it,
+    so the uv plane of a hit must equal it at the hit point."""
+    p = np.asarray(p, np.float64)
+    return np.stack([0.11 * p[..., 0] - 0.05 * p[..., 1] + 0.5, 0.07 * p[..., 2] + 0.09 * p[..., 1] + 0.25], -1)
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
+def test_uv_plane_interpolates_the_corner_texcoords_at_the_primary_hit(accel):
+    """rt_set_triangle_texcoords + the uv plane of rt_render_frame_planes (the reference parses `vt` and drops
+    it, so there is no reference output: the check is the interpolation's defining property)."""
+    spec, _ = _smooth_scene()
+    cam = rt.Camera(pitch=0.05)
+    W, H = 160, 120
+    first = len(spec.analytic)
+    corner_uv = _affine_uv(spec.verts[spec.indices].reshape(-1, 3, 3)).astype(np.float32)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, accel)
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        none = ctx.render_frame_planes(W, H, max_depth=1)
+        assert not none["uv"].any()                                        # nothing loaded: zeros
+        ctx.set_triangle_texcoords(corner_uv)
+        g = ctx.render_frame_planes(W, H, max_depth=1)
+        with pytest.raises(rt.RtError):
+            ctx.set_triangle_texcoords(corner_uv[:-1])
+        for k in ("rgb8", "hit_id", "hit_t", "normal"):                     # the image does not depend on them
+            assert np.array_equal(g[k].view(np.uint8), none[k].view(np.uint8)), k
+        ctx.set_triangle_texcoords(None)
+        assert not ctx.render_frame_planes(W, H, max_depth=1)["uv"].any()
+    tri = g["hit_id"] >= first
+    assert tri.sum() > 2000 and not g["uv"][~tri].any()                     # misses, spheres and the plane: (0, 0)
+    ys, xs = np.nonzero(tri)
+    o = np.asarray(cam.origin, np.float64)
+    d = np.stack([xs * np.float64(np.float32(cam.pitch)) + cam.off_x, ys * np.float64(np.float32(cam.pitch)) + cam.off_y,
+                  np.full(len(xs), cam.plane_z)], -1) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hit = o + d * g["hit_t"][tri][:, None].astype(np.float64)
+    assert np.abs(g["uv"][tri] - _affine_uv(hit)).max() < 2e-4
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_depth_zero_no_lights_no_hits_and_empty_mesh():
     cam = rt.Camera(pitch=0.05)
@@ -745,6 +787,30 @@ def test_host_smooth_flag_shades_with_the_vn_normals_of_the_file():
     d = np.abs(img.astype(int) - r["rgb8"].astype(int)).max(-1)
     assert d.max() <= 1 and (d == 0).mean() >= MIN_FRACTION
     assert (hid >= 3).sum() > 2000
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_exr_carries_u_and_v_when_the_obj_has_texcoords():
+    """--relaxed --exr on an OBJ with `f v/vt`: the vt coordinates reach rt_set_triangle_texcoords and the EXR
+    gains u and v channels, equal to the affine function the file's coordinates were sampled from."""
+    v, i, _ = scenes.uv_sphere((0.0, -1.0, 1.0), 2.0, 8, 12)
+    uv = _affine_uv(v)
+    with tempfile.TemporaryDirectory() as td:
+        obj, exr = os.path.join(td, "s.obj"), os.path.join(td, "f.exr")
+        with open(obj, "w") as f:
+            for p in v:
+                f.write("v %.9g %.9g %.9g\n" % tuple(p))
+            for t in uv:
+                f.write("vt %.9g %.9g\n" % tuple(t))
+            for k in range(0, len(i), 3):
+                f.write("f " + " ".join("%d/%d" % (j + 1, j + 1) for j in i[k:k + 3]) + "\n")
+        subprocess.run([HOST_BIN, "--obj", obj, "--relaxed", "--no-mirror", "--width", "320", "--height", "240", "--exr", exr,
+                        "--out", ""], check=True, capture_output=True, timeout=120)
+        ch = _read_exr(exr)
+    assert "u" in ch and "v" in ch
+    tri = ch["id"] >= 3 + 1                                                 # EXR ids are hit id + 1; 3 analytic primitives
+    assert tri.sum() > 2000 and not ch["u"][~tri].any() and not ch["v"][~tri].any()
+    assert ch["u"][tri].std() > 0.01 and np.isfinite(ch["u"]).all() and np.isfinite(ch["v"]).all()
 
 
 # ------------------------------------------------------------------ many lights / no lights through the LBVH stages
