@@ -33,6 +33,8 @@ struct rt_ctx {
     int32_t *d_indices = nullptr;   // kept from rt_set_mesh for rt_update_mesh_vertices
     float4 *d_tri_vn = nullptr;     // opt-in shading normals, 3 per triangle (rt_set_triangle_normals)
     float2 *d_tri_vt = nullptr;     // texture coordinates, 3 per triangle (rt_set_triangle_texcoords)
+    void *d_stage = nullptr;        // upload staging of rt_update_*: kept between calls (one per tick in an animation)
+    size_t stage_cap = 0;
     int n_mesh_verts = 0;
     DevMaterial *d_mats = nullptr;
     int n_mats = 0;
@@ -448,6 +450,7 @@ void rt_destroy(rt_ctx *c)
     free_workspace(c->ws);
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
+    if (c->d_stage) (void)hipFree(c->d_stage);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -601,6 +604,17 @@ int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indic
 
 namespace {
 
+void *stage(rt_ctx *c, size_t bytes)
+{
+    if (bytes > c->stage_cap) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->stage_cap = 0;
+        if (hipMalloc(&c->d_stage, bytes) != hipSuccess) return nullptr;
+        c->stage_cap = bytes;
+    }
+    return c->d_stage;
+}
+
 // After the Triangle constructor has run again over moved vertices: refit the hierarchy if one exists
 // (or build it if this frame's settings want one and none is there).
 int after_vertex_update(rt_ctx *c)
@@ -627,8 +641,8 @@ int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
     if (c->n_tris == 0 || n_tris != c->n_tris) return fail(RT_E_STATE, "triangle count does not match the loaded triangles");
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
-    float *d_v = nullptr;
-    if (hipMalloc((void **)&d_v, sizeof(float) * 9 * (size_t)n_tris) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
+    float *d_v = (float *)stage(c, sizeof(float) * 9 * (size_t)n_tris);
+    if (!d_v) return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
     int rc = RT_OK;
     if (hipMemcpyAsync(d_v, tri_verts, sizeof(float) * 9 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream) != hipSuccess)
         rc = fail(RT_E_DEVICE, "upload triangle vertices");
@@ -636,7 +650,6 @@ int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
         rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
     if (rc == RT_OK) rc = after_vertex_update(c);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d_v);
     return rc;
 }
 
@@ -648,13 +661,11 @@ int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
     if (n_verts != c->n_mesh_verts) return fail(RT_E_STATE, "vertex count does not match the loaded mesh");
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
-    float *d_v = nullptr;
-    int *d_bad = nullptr;
-    if (hipMalloc((void **)&d_v, sizeof(float) * 3 * (size_t)n_verts) != hipSuccess ||
-        hipMalloc((void **)&d_bad, sizeof(int)) != hipSuccess) {
-        if (d_v) (void)hipFree(d_v);
-        return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
-    }
+    // staging: the vertices, then one word for the index check of the set-up kernel
+    const size_t vbytes = (sizeof(float) * 3 * (size_t)n_verts + 15) & ~(size_t)15;
+    float *d_v = (float *)stage(c, vbytes + sizeof(int));
+    if (!d_v) return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
+    int *d_bad = (int *)((char *)d_v + vbytes);
     int rc = RT_OK;
     if (hipMemcpyAsync(d_v, verts, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemsetAsync(d_bad, 0, sizeof(int), c->stream) != hipSuccess)
@@ -664,8 +675,6 @@ int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
         rc = fail(RT_E_DEVICE, "triangle set-up launch failed");
     if (rc == RT_OK) rc = after_vertex_update(c);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d_v);
-    (void)hipFree(d_bad);
     return rc;
 }
 
