@@ -93,22 +93,34 @@ __device__ inline void tri_box(const float4 *__restrict__ tri_mt, int i, float l
     }
 }
 
-__global__ void k_bounds(const float4 *__restrict__ tri_mt, int n, unsigned int *bounds /*[6] ordered: lo xyz, hi xyz*/)
+// Grid-stride: every thread folds many triangles, a wave reduces by shuffles, the block by LDS, and one lane per
+// block issues the six atomics (atomics to one cache line retire at about 90 per microsecond on this chip: one set
+// per wave of triangles made this kernel half of a refit).
+__global__ __launch_bounds__(256) void k_bounds(const float4 *__restrict__ tri_mt, int n, unsigned int *bounds /*[6] ordered: lo xyz, hi xyz*/)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_lo[4][3], s_hi[4][3];
     float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-    if (i < n) tri_box(tri_mt, i, lo, hi);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float l[3], h[3];
+        tri_box(tri_mt, i, l, h);
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], l[k]); hi[k] = fmaxf(hi[k], h[k]); }
+    }
     for (int k = 0; k < 3; k++) {
         for (int off = 32; off > 0; off >>= 1) {
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&bounds[k], float_to_ordered(lo[k]));
-            atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
-        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; k++) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = s_lo[0][k], b = s_hi[0][k];
+        for (int w = 1; w < 4; w++) { a = fminf(a, s_lo[w][k]); b = fmaxf(b, s_hi[w][k]); }
+        atomicMin(&bounds[k], float_to_ordered(a));
+        atomicMax(&bounds[3 + k], float_to_ordered(b));
     }
 }
 
@@ -196,6 +208,51 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(T *data, int m, T *tota
         __syncthreads();
     }
     if (total && tid == 0) *total = carry_s;
+}
+
+// The same scan over many blocks, for inputs where one block would take hundreds of microseconds:
+//   k_scan_partials   sum of every 4096-element chunk
+//   k_scan_exclusive  (one block) scan of the chunk sums, grand total
+//   k_scan_chunks     scan inside every chunk, offset by its chunk's prefix
+constexpr int SCAN_CHUNK = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_partials(const T *__restrict__ data, int m, T *partial)
+{
+    __shared__ T wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = blockIdx.x * SCAN_CHUNK + tid * 4;
+    T s = 0;
+    for (int k = 0; k < 4; k++) s += (i0 + k < m) ? data[i0 + k] : (T)0;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) wave_sum[w] = s;
+    __syncthreads();
+    if (tid == 0) {
+        T t = 0;
+        for (int k = 0; k < 16; k++) t += wave_sum[k];
+        partial[blockIdx.x] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_chunks(T *data, int m, const T *__restrict__ partial_scanned)
+{
+    __shared__ T wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = blockIdx.x * SCAN_CHUNK + tid * 4;
+    T v[4], s = 0;
+    for (int k = 0; k < 4; k++) { v[k] = (i0 + k < m) ? data[i0 + k] : (T)0; s += v[k]; }
+    T incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        T t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sum[w] = incl;
+    __syncthreads();
+    T wprefix = 0;
+    for (int k = 0; k < w; k++) wprefix += wave_sum[k];
+    T excl = partial_scanned[blockIdx.x] + wprefix + incl - s;
+    for (int k = 0; k < 4; k++) { if (i0 + k < m) data[i0 + k] = excl; excl += v[k]; }
 }
 
 __global__ __launch_bounds__(64) void k_sort_scatter(const unsigned long long *__restrict__ keys_in,
@@ -723,6 +780,21 @@ template <typename T> struct DevBuf {
 
 inline int blocks_for(int n, int bs) { return (n + bs - 1) / bs; }
 
+// Exclusive scan of data[0..m) on `stream`; scratch holds blocks_for(m, SCAN_CHUNK) elements.  Small inputs take
+// the one-block kernel (one launch), large ones the three-launch form.
+template <typename T>
+void scan_exclusive(T *data, int m, T *total, T *scratch, hipStream_t stream)
+{
+    if (m <= 8 * SCAN_CHUNK || !scratch) {
+        hipLaunchKernelGGL(k_scan_exclusive<T>, dim3(1), dim3(1024), 0, stream, data, m, total);
+        return;
+    }
+    const int chunks = blocks_for(m, SCAN_CHUNK);
+    hipLaunchKernelGGL(k_scan_partials<T>, dim3(chunks), dim3(1024), 0, stream, (const T *)data, m, scratch);
+    hipLaunchKernelGGL(k_scan_exclusive<T>, dim3(1), dim3(1024), 0, stream, scratch, chunks, total);
+    hipLaunchKernelGGL(k_scan_chunks<T>, dim3(chunks), dim3(1024), 0, stream, data, m, (const T *)scratch);
+}
+
 }  // namespace
 
 // What a refit needs from the build: the binary tree over the sorted triangles and the numbering of
@@ -804,6 +876,10 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     A(depth.alloc(n)); A(scalars.alloc(4)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
     DevBuf<QuantGrid> grid;
     A(grid.alloc(1));
+    DevBuf<unsigned int> scan_u32;               // chunk sums of the multi-block scans
+    DevBuf<unsigned long long> scan_u64;
+    A(scan_u32.alloc((size_t)blocks_for(256 * n_tiles, 4096) + 1));
+    A(scan_u64.alloc((size_t)blocks_for(n, 4096) + 1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->qnodes, sizeof(BvhNodeQ) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES)));
@@ -820,13 +896,13 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
 
     const int B = 256, G = blocks_for(n, B);
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds.p);
-    hipLaunchKernelGGL(k_bounds, dim3(G), dim3(B), 0, stream, tri_mt, n, bounds.p);
+    hipLaunchKernelGGL(k_bounds, dim3(G < 256 ? G : 256), dim3(256), 0, stream, tri_mt, n, bounds.p);
     hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, tri_mt, n, bounds.p, keys[0].p, vals[0].p);
     int cur = 0;
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
         hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, n, shift, hist.p, n_tiles);
-        hipLaunchKernelGGL(k_scan_exclusive<unsigned int>, dim3(1), dim3(1024), 0, stream, hist.p, 256 * n_tiles, (unsigned int *)nullptr);
+        scan_exclusive<unsigned int>(hist.p, 256 * n_tiles, (unsigned int *)nullptr, scan_u32.p, stream);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, vals[cur].p, n, shift, hist.p,
                            n_tiles, keys[cur ^ 1].p, vals[cur ^ 1].p);
         cur ^= 1;
@@ -867,7 +943,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
             const int g = blocks_for(C, B);
             hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, cid[cc].p, C, box_lo.p, box_hi.p, nn.p);
             hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(B), 0, stream, nn.p, C, flags.p);
-            hipLaunchKernelGGL(k_scan_exclusive<unsigned long long>, dim3(1), dim3(1024), 0, stream, flags.p, C, totals.p);
+            scan_exclusive<unsigned long long>(flags.p, C, totals.p, scan_u64.p, stream);
             hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(B), 0, stream, cid[cc].p, nn.p, flags.p, C, n, created, cid[cc ^ 1].p,
                                children.p, parent.p, size.p, box_lo.p, box_hi.p);
             unsigned long long tot = 0;
@@ -982,7 +1058,7 @@ int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out,
     const int B = 256, G = blocks_for(n, B), GI = blocks_for(n - 1, B);
     const int *leafpos = t->ploc ? t->leafpos : (const int *)nullptr;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, t->bounds);
-    hipLaunchKernelGGL(k_bounds, dim3(G), dim3(B), 0, stream, tri_mt, n, t->bounds);
+    hipLaunchKernelGGL(k_bounds, dim3(G < 256 ? G : 256), dim3(256), 0, stream, tri_mt, n, t->bounds);
     hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, n, t->bounds, t->box_lo, t->box_hi);
     for (int level = t->max_depth; level >= 0; level--)
         hipLaunchKernelGGL(k_refit_level, dim3(GI), dim3(B), 0, stream, t->children, t->depth, n - 1, level, t->box_lo, t->box_hi);
