@@ -449,14 +449,17 @@ __global__ void k_dfs_finish(const int *__restrict__ offset, const int *__restri
     }
 }
 
-__global__ void k_node_depth(const int *__restrict__ parent, int n_internal, int *depth, int *max_depth)
+__global__ __launch_bounds__(256) void k_node_depth(const int *__restrict__ parent, int n_internal, int *depth, int *max_depth)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_internal) return;
-    int d = 0;
-    for (int p = parent[i]; p >= 0; p = parent[p]) d++;
-    depth[i] = d;
-    atomicMax(max_depth, d);
+    int deepest = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_internal; i += gridDim.x * blockDim.x) {
+        int d = 0;
+        for (int p = parent[i]; p >= 0; p = parent[p]) d++;
+        depth[i] = d;
+        deepest = max(deepest, d);
+    }
+    for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, __shfl_xor(deepest, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_depth, deepest);     // one per wave of a fixed grid, not one per node
 }
 
 // Leaf boxes: the intersector's triangle, padded so that rounding in the
@@ -522,13 +525,12 @@ __global__ void k_pre_level(const int2 *__restrict__ children, const int *__rest
 // Traversal nodes.  A child whose sorted range holds <= leaf_max triangles becomes
 // a leaf reference ~(first*8 + count-1); nodes inside such a subtree are never
 // reached and are left zeroed.
-__global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
+__device__ __forceinline__ int emit_node(int i, const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
                        const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre,
-                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
+                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
+    if (i >= n - 1) return 0;
     // 15-bit lattice over the root box (the union of all padded leaf boxes)
     const float4 rlo = box_lo[0], rhi = box_hi[0];
     const float gb[3] = { rlo.x, rlo.y, rlo.z };
@@ -543,7 +545,7 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
         // parent, or lies inside such a leaf: never traversed.  Ranges nest, so every
         // node spanning more than leaf_max triangles has only live ancestors.
         int2 r = range[i];
-        if (r.y - r.x + 1 <= leaf_max) return;
+        if (r.y - r.x + 1 <= leaf_max) return 0;
     }
     int2 c = children[i];
     int enc[2];
@@ -584,8 +586,21 @@ __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict
     qn.a = make_uint4(w[0], w[1], w[2], w[3]);
     qn.b = make_uint4(w[4], w[5], (unsigned int)enc[0], (unsigned int)enc[1]);
     qnodes[pre[i]] = qn;
-    atomicMax(live_depth, depth[i] + 1);
+    return depth[i] + 1;
 }
+
+// Every lane reaches the reduction: one atomic per wave for the depth of the emitted tree.
+__global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
+                       const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
+                       const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre,
+                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
+{
+    int d = emit_node(blockIdx.x * blockDim.x + threadIdx.x, children, range, parent, depth, n, leaf_max, box_lo, box_hi, leafpos, pre,
+                      nodes, qnodes, grid);
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(live_depth, d);
+}
+
 
 // ---- 4-wide nodes.  A wide node is rooted at a binary node; its children are found by opening, up to
 // twice, the inner child with the largest surface area (the one a ray is most likely to enter), so that big
@@ -709,13 +724,12 @@ __device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, c
     }
 }
 
-__global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
+__device__ __forceinline__ int emit_wide_node(int i, const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
                             const int4 *__restrict__ wkids, int n, int leaf_max, const float4 *__restrict__ box_lo,
                             const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
-                            const int *__restrict__ slot, BvhNode4 *wnodes, int *wide_depth)
+                            const int *__restrict__ slot, BvhNode4 *wnodes)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || live[i] == 0 || root[i] == 0) return;
+    if (i >= n - 1 || live[i] == 0 || root[i] == 0) return 0;
     const float4 rlo = box_lo[0], rhi = box_hi[0];
     const float gb[3] = { rlo.x, rlo.y, rlo.z };
     float gs[3] = { (rhi.x - rlo.x) * (1.0f / 32767.0f), (rhi.y - rlo.y) * (1.0f / 32767.0f), (rhi.z - rlo.z) * (1.0f / 32767.0f) };
@@ -749,8 +763,20 @@ __global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restric
     nd.c = make_uint4(w[8], w[9], w[10], w[11]);
     nd.d = make_uint4((unsigned)ref[0], (unsigned)ref[1], (unsigned)ref[2], (unsigned)ref[3]);
     wnodes[wide_index(i, root, slot, pre4)] = nd;
-    atomicMax(wide_depth, root[i]);
+    return root[i];
 }
+
+__global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
+                            const int4 *__restrict__ wkids, int n, int leaf_max, const float4 *__restrict__ box_lo,
+                            const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
+                            const int *__restrict__ slot, BvhNode4 *wnodes, int *wide_depth)
+{
+    int d = emit_wide_node(blockIdx.x * blockDim.x + threadIdx.x, range, live, root, wkids, n, leaf_max, box_lo, box_hi, leafpos, pre4,
+                           slot, wnodes);
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(wide_depth, d);
+}
+
 
 __global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals,
                               const int *__restrict__ order, int n, float4 *bvh_tri)
@@ -919,7 +945,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     if (!ploc) {
         hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
                            parent.p);
-        hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
+        hipLaunchKernelGGL(k_node_depth, dim3(min(blocks_for(n - 1, 256), 2048)), dim3(256), 0, stream, parent.p, n - 1, depth.p, scalars.p);
         RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipStreamSynchronize(stream), err);
         for (int level = max_depth; level >= 0; level--)
@@ -959,7 +985,7 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
             C = kept;
             cc ^= 1;
         }
-        hipLaunchKernelGGL(k_node_depth, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, parent.p, n - 1, depth.p, scalars.p);
+        hipLaunchKernelGGL(k_node_depth, dim3(min(blocks_for(n - 1, 256), 2048)), dim3(256), 0, stream, parent.p, n - 1, depth.p, scalars.p);
         RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipStreamSynchronize(stream), err);
         for (int level = 0; level <= max_depth; level++)
