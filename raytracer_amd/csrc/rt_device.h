@@ -78,6 +78,25 @@ __device__ __forceinline__ bool tri_raycast(F3 v1, F3 e1, F3 e2, F3 o, F3 d, flo
     return t > 0.0001f;
 }
 
+// Guarded builds (-DRT_GUARD=1) are for trying kernel changes: every index that comes out of device data (queue
+// positions from region counts, node and triangle references, pixels carried by rays, stack spill slots) is checked
+// against its array first.  A bad one is replaced by 0 and counted in FrameCounters::guard_hits, which rt_get_stats
+// reports as an error, instead of faulting the card.  In a normal build RTG(i, limit) is just (i).
+#ifndef RT_GUARD
+#define RT_GUARD 0
+#endif
+#if RT_GUARD
+__device__ __forceinline__ unsigned long long rt_guard(unsigned long long i, unsigned long long limit, FrameCounters *c)
+{
+    if (i < limit) return i;
+    atomicAdd(&c->guard_hits, 1u);
+    return 0ull;
+}
+#define RTG(i, limit) rt_guard((unsigned long long)(i), (unsigned long long)(limit), A.counters)
+#else
+#define RTG(i, limit) (i)
+#endif
+
 struct Tally { unsigned box, tri, analytic; };
 
 __device__ __forceinline__ unsigned long long lanemask_lt()

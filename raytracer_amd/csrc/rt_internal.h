@@ -99,6 +99,7 @@ struct FrameCounters {
     unsigned long long node_iters, node_lanes, leaf_iters, leaf_lanes, refill_events, refill_lanes;
     unsigned long long step_hist[16];             // rays by traversal steps taken: bin = bit length of the step count
     unsigned int max_steps, pad_steps;
+    unsigned int guard_hits, pad_guard;          // RT_GUARD builds: indices found outside their array (0 otherwise)
 };
 
 // ------------------------------------------------------------------ host-side state

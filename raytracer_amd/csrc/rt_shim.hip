@@ -868,6 +868,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     FrameCounters fc;
     if (hipMemcpy(&fc, c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(RT_E_DEVICE, "read frame counters");
+    if (fc.guard_hits)      // only a guarded build (-DRT_GUARD=1) ever counts these
+        return fail(RT_E_DEVICE, "guarded build: " + std::to_string(fc.guard_hits) + " out-of-range indices were caught in the last frame");
     out->rays_primary = c->last_primary;
     out->rays_shadow = fc.rays_shadow;
     out->rays_reflect = fc.rays_reflect;

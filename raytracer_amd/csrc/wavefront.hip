@@ -106,6 +106,10 @@ struct TraceArgs {
     int *overflow;                  // [WF_OVF][total_lanes]
     unsigned int total_lanes;
     FrameCounters *counters;
+    // array sizes, read by guarded builds only
+    unsigned long long q_cap, q2_cap;   // entries of q_o/q_d and q2_o/q2_d
+    unsigned int n_pix;                 // entries of the hit and occlusion planes
+    unsigned int n_wnodes;              // entries of sc.wnodes
     unsigned long long *wave_times; // diagnostic (RT_WF_TIMES): [wave][3] 100 MHz clock at start, when nothing was left to claim, at exit
 };
 
@@ -160,7 +164,7 @@ void k_trace(TraceArgs A)
 
     auto push = [&](int v) {
         if (sp < WF_LDS_STACK) stack[sp * BLOCK] = v;
-        else ovf[(size_t)(sp - WF_LDS_STACK) * A.total_lanes] = v;
+        else ovf[(size_t)RTG(sp - WF_LDS_STACK, WF_OVF) * A.total_lanes] = v;
         sp++;
     };
     auto pop = [&]() {
@@ -171,12 +175,12 @@ void k_trace(TraceArgs A)
             // The rare deep entry comes back through an explicit global load: left as two plain C++
             // loads, hipcc merges the LDS and the global branch into ONE flat_load on a generic
             // pointer, and every pop then pays the flat path's latency and waits.
-            const int *p = ovf + (size_t)(sp - WF_LDS_STACK) * A.total_lanes;
+            const int *p = ovf + (size_t)RTG(sp - WF_LDS_STACK, WF_OVF) * A.total_lanes;
             int v;
             asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
             node = v;
         }
-        if (node == NODE_SENTINEL && (MODE == 0 || (MODE == 2 && bit < 0))) A.hits[slot] = make_float2(best_t, __int_as_float(best_id));
+        if (node == NODE_SENTINEL && (MODE == 0 || (MODE == 2 && bit < 0))) A.hits[RTG(slot, A.n_pix)] = make_float2(best_t, __int_as_float(best_id));
     };
 
     for (;;) {
@@ -225,7 +229,7 @@ void k_trace(TraceArgs A)
                 bool live = true;
                 const bool unit_any = MODE == 1 || (MODE == 2 && seg < A.n_segments);     // wave-uniform
                 if (unit_any) {
-                    const size_t q = (size_t)seg * A.seg_stride + my;
+                    const size_t q = (size_t)RTG((size_t)seg * A.seg_stride + my, A.q_cap);
                     const float4 qo = A.q_o[q], qd = A.q_d[q];
                     o = f3(qo); d = f3(qd);
                     slot = (unsigned)__float_as_int(qo.w);
@@ -235,7 +239,8 @@ void k_trace(TraceArgs A)
                     o = pr.o; d = pr.d; live = pr.live;
                     slot = (unsigned)pr.pixel;
                 } else {
-                    const float4 qo = (MODE == 2 ? A.q2_o : A.q_o)[my], qd = (MODE == 2 ? A.q2_d : A.q_d)[my];
+                    const size_t q = (size_t)RTG(my, MODE == 2 ? A.q2_cap : A.q_cap);
+                    const float4 qo = (MODE == 2 ? A.q2_o : A.q_o)[q], qd = (MODE == 2 ? A.q2_d : A.q_d)[q];
                     o = f3(qo); d = f3(qd);
                     slot = (unsigned)__float_as_int(qo.w);
                     if (MODE == 2) bit = -1;
@@ -281,7 +286,7 @@ void k_trace(TraceArgs A)
                 {
                     // 32-bit byte offset from the uniform base: one shift instead of 64-bit address arithmetic
                     // (the builder keeps the wide node array below 4 GiB)
-                    const uint4 *np = (const uint4 *)((const char *)sc.wnodes + (unsigned)node * 64u);
+                    const uint4 *np = (const uint4 *)((const char *)sc.wnodes + (unsigned)RTG(node, A.n_wnodes) * 64u);
                     qa = np[0]; qb = np[1]; qc = np[2]; qd = np[3];
                 }
                 float dk[4];
@@ -377,7 +382,7 @@ void k_trace(TraceArgs A)
                 }
                 for (;;) {
                 // 32-bit byte offset (48 bytes per triangle; the builder's triangle limit keeps it below 4 GiB)
-                const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)tri_i * 48u);
+                const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)RTG(tri_i, sc.n_tris) * 48u);
                 const float4 v1 = tp[0];
                 const F3 e1 = f3(tp[1]), e2 = f3(tp[2]);
                 float t;
@@ -387,7 +392,7 @@ void k_trace(TraceArgs A)
                 tri_left--;
                 if (MODE == 1 || (MODE == 2 && bit >= 0)) {
                     if (h) {                                       // main.cpp:183-186: any hit blocks the light
-                        atomicOr(&A.occ[slot], 1u << bit);
+                        atomicOr(&A.occ[RTG(slot, A.n_pix)], 1u << (RTG(bit, 32) & 31));
                         node = NODE_SENTINEL;
                         tri_left = 0;
                     }
@@ -469,11 +474,12 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
             const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, slot);
             r.o = pr.o; r.d = pr.d; r.pixel = pr.pixel; r.live = pr.live;
         } else {
-            const float4 qo = A.q_o[slot], qd = A.q_d[slot];
+            const float4 qo = A.q_o[RTG(slot, A.slots_cap)], qd = A.q_d[RTG(slot, A.slots_cap)];
             r.o = f3(qo); r.d = f3(qd); r.pixel = __float_as_int(qo.w);
         }
     }
     if (r.live) {
+        r.pixel = (int)RTG(r.pixel, A.n_pixels);
         const float2 h = A.hits[r.pixel];
         r.t = h.x; r.id = __float_as_int(h.y);
         // never index scene arrays with an id outside the scene
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             unsigned int total;
             const unsigned int rank = block_rank(spawn, s_cnt, total);
             if (spawn) {
-                const size_t dst = (size_t)region * REGION + rank;
+                const size_t dst = (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
                 A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
             }
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             unsigned int total;
             const unsigned int rank = block_rank(want, s_cnt, total);
             if (want) {
-                const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)region * REGION + rank;
+                const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.sq_o[q] = make_float4(so.x, so.y, so.z, __int_as_float(r.pixel));
                 A.sq_d[q] = make_float4(L.x, L.y, L.z, __int_as_float(li - l0));
             }
@@ -612,6 +618,9 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     t.n_slots = n_slots; t.n_regions = n_regions;
     t.overflow = ws.overflow; t.total_lanes = (unsigned)trace_grid * BLOCK;
     t.counters = ws.counters;
+    t.n_pix = (unsigned)n_pixels;
+    t.n_wnodes = (unsigned)(WIDE_TOP_NODES + (scene.n_tris > 1 ? scene.n_tris - 1 : 1));
+    t.q_cap = t.q2_cap = (unsigned long long)ws.pixels_cap;
 
     ShadeArgs s;
     s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = n_rows; s.n_pixels = n_pixels; s.rows = fp.rows;
@@ -677,11 +686,13 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         t.hits = hits_of(close_level);
         if (mode == 0) {
             t.q_o = ws.queue_o[level & 1]; t.q_d = ws.queue_d[level & 1];
+            t.q_cap = (unsigned long long)ws.pixels_cap;
             t.counts = ws.rq_counts[level & 1];
             t.occ = nullptr;
             t.n_segments = 1; t.seg_stride = 0;
         } else {
             t.q_o = ws.sq_o; t.q_d = ws.sq_d;
+            t.q_cap = (unsigned long long)ws.slots_cap * (unsigned long long)(ws.seg_cap ? ws.seg_cap : 1);
             t.counts = ws.sq_counts;
             t.occ = occ_of(level, chunk);
             t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;

@@ -10,8 +10,16 @@ for p in (HERE, ROOT):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--rt-lib", default="", help="another build of librt_amd.so to test (e.g. a guarded variant, "
+                                                   "raytracer_amd/variants/guard.so built with -DRT_GUARD=1)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    lib = config.getoption("--rt-lib")
+    if lib:      # read by raytracer_amd when it loads the library; the host binary keeps its own link
+        os.environ["RT_AMD_LIB"] = os.path.abspath(lib)
 
 
 @pytest.fixture(scope="session")
