@@ -870,9 +870,41 @@ void lbvh_free(LbvhResult *r)
     *r = LbvhResult();
 }
 
+namespace {
+
+// The two timing events of a build or refit, destroyed on every way out.
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create()
+    {
+        hipError_t e = hipEventCreate(&a);
+        if (e == hipSuccess) e = hipEventCreate(&b);
+        return e;
+    }
+    ~EventPair()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err);
+
+}  // namespace
+
+// Every failure leaves `out` empty: a half-built hierarchy (arrays allocated, depth and leaf size unset) is never kept.
 int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err)
 {
     lbvh_free(out);
+    const int rc = lbvh_build_impl(tri_mt, n, leaf_max, builder, stream, out, err);
+    if (rc != RT_OK) lbvh_free(out);
+    return rc;
+}
+
+namespace {
+
+int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err)
+{
     if (n < 2) {
         if (err) *err = "lbvh_build needs at least 2 triangles";
         return RT_E_INVALID;
@@ -915,9 +947,9 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
         lbvh_free(out);
         return RT_E_NOMEM;
     }
-    hipEvent_t ev0, ev1;
-    RT_HIP_CHECK(hipEventCreate(&ev0), err);
-    RT_HIP_CHECK(hipEventCreate(&ev1), err);
+    EventPair ev;
+    RT_HIP_CHECK(ev.create(), err);
+    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
     RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
 
     const int B = 256, G = blocks_for(n, B);
@@ -1046,8 +1078,6 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     RT_HIP_CHECK(hipStreamSynchronize(stream), err);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     out->n_nodes = n - 1;
     out->depth = live_depth;
     out->wide_depth = wide_depth;
@@ -1067,6 +1097,8 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream
     return RT_OK;
 }
 
+}  // namespace
+
 // New vertex positions under the same tree: leaf boxes, bottom-up unions, then the node arrays and the
 // triangle copy are written again.  The lattice follows the new root box.  Which triangles share a leaf
 // does not change, so a large deformation costs traversal steps, never correctness.
@@ -1077,9 +1109,9 @@ int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out,
         if (err) *err = "lbvh_refit: no hierarchy over this many triangles";
         return RT_E_STATE;
     }
-    hipEvent_t ev0, ev1;
-    RT_HIP_CHECK(hipEventCreate(&ev0), err);
-    RT_HIP_CHECK(hipEventCreate(&ev1), err);
+    EventPair ev;
+    RT_HIP_CHECK(ev.create(), err);
+    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
     RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
     const int B = 256, G = blocks_for(n, B), GI = blocks_for(n - 1, B);
     const int *leafpos = t->ploc ? t->leafpos : (const int *)nullptr;
@@ -1100,8 +1132,6 @@ int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out,
     RT_HIP_CHECK(hipStreamSynchronize(stream), err);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     out->ms_build = ms;
     return RT_OK;
 }

@@ -53,7 +53,15 @@ struct rt_ctx {
     bool frame_valid = false;
     int last_levels = 0, last_launches = 0, last_accel = 0;
     bool last_wavefront = false;
+    bool last_timed = false;                 // the last frame recorded its device events
     uint64_t last_primary = 0;
+    FrameCounters *last_counters = nullptr;  // where the last frame counted its rays
+    // Renders are asynchronous and may run on a caller's stream: frame_done is recorded behind every enqueued
+    // frame, and everything that rewrites what a frame reads (scene, hierarchy, workspace, the captured graph)
+    // waits for it first.
+    hipEvent_t frame_done = nullptr;
+    bool frame_pending = false;
+    hipStream_t last_stream = nullptr;
 };
 
 namespace {
@@ -89,8 +97,17 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Wait for everything this context has enqueued, on its own stream and on any caller stream a frame went to.
+void quiesce(rt_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    if (c->frame_pending && c->frame_done) (void)hipEventSynchronize(c->frame_done);
+    c->frame_pending = false;
+}
+
 void drop_graph(rt_ctx *c)
 {
+    if (c->graph_exec && c->frame_pending && c->frame_done) (void)hipEventSynchronize(c->frame_done);   // it may still be replaying
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
     c->graph_key.clear();
@@ -133,6 +150,7 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
 {
     const bool wavefront = pipe == 2;
     FrameWorkspace &ws = c->ws;
+    // (hipFree of a buffer waits for the device by itself; the frees below are the only way a buffer goes away)
     if (!ws.counters) {
         if (hipMalloc((void **)&ws.counters, sizeof(FrameCounters)) != hipSuccess)
             return fail(RT_E_NOMEM, "hipMalloc(counters) failed");
@@ -272,8 +290,11 @@ int ensure_accel(rt_ctx *c, int *accel)
         int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->opt_builder, c->stream, &c->bvh, &err);
         if (rc != RT_OK) return fail(rc, err);
         c->bvh.builder = c->opt_builder;
-        if (c->bvh.depth > 64)
+        if (c->bvh.depth > 64) {
+            // do not keep a hierarchy no kernel may traverse: the next call must fail the same way
+            lbvh_free(&c->bvh);
             return fail(RT_E_LIMIT, "LBVH deeper than the 64-entry traversal stack");
+        }
     }
     *accel = want ? 1 : 0;
     return RT_OK;
@@ -306,6 +327,16 @@ int validate_rows(int W, int H, const rt_rowset *r)
     return RT_OK;
 }
 
+DevScene device_scene(const rt_ctx *c, int accel)
+{
+    DevScene sc;
+    sc.analytic = c->d_analytic; sc.lights = c->d_lights;
+    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
+    return sc;
+}
+
 int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
                   void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false)
 {
@@ -321,12 +352,11 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     const bool wavefront = pipe != 1;
     const size_t slots = (size_t)((W + 7) / 8) * (size_t)((rows->n_rows + 7) / 8) * 64;
     if (int rc = ensure_workspace(c, pixels, slots, max_depth + 1, pipe, host_outputs)) return rc;
+    // one workspace serves every frame of this context: a frame on another stream than the last one waits for it
+    if (c->frame_pending && stream != c->last_stream && hipStreamWaitEvent(stream, c->frame_done, 0) != hipSuccess)
+        return fail(RT_E_DEVICE, "hipStreamWaitEvent failed");
 
-    DevScene sc;
-    sc.analytic = c->d_analytic; sc.lights = c->d_lights;
-    sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
-    sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
+    const DevScene sc = device_scene(c, accel);
 
     FrameParams fp;
     fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
@@ -398,6 +428,11 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
     }
     if (rc != RT_OK) return fail(rc, err);
+    if (hipEventRecord(c->frame_done, stream) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
+    c->frame_pending = true;
+    c->last_stream = stream;
+    c->last_counters = c->ws.counters;
+    c->last_timed = fp.timing != 0;
     c->frame_valid = true;
     c->last_levels = max_depth + 1;
     c->last_launches = launches;
@@ -436,6 +471,12 @@ rt_ctx *rt_create(int device_ordinal)
         delete c;
         return nullptr;
     }
+    if (hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming) != hipSuccess) {
+        fail(RT_E_DEVICE, "hipEventCreate failed");
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
     default_camera(&c->cam);
     return c;
 }
@@ -444,13 +485,14 @@ void rt_destroy(rt_ctx *c)
 {
     if (!c) return;
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     drop_graph(c);
     free_triangles(c);
     free_workspace(c->ws);
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->frame_done) (void)hipEventDestroy(c->frame_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -505,7 +547,7 @@ int rt_set_analytic(rt_ctx *c, const rt_analytic *prims, int n)
         if (p.is_light) lights.push_back(i);
     }
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
     c->d_analytic = nullptr; c->d_lights = nullptr; c->n_analytic = 0; c->n_lights = 0;
@@ -528,7 +570,7 @@ int rt_set_triangles(rt_ctx *c, const float *tri_verts, int n_tris, const rt_mat
     if (n_tris < 0 || (n_tris > 0 && !tri_verts)) return fail(RT_E_INVALID, "bad triangle array");
     if ((long long)n_tris * 8 >= (1ll << 31)) return fail(RT_E_LIMIT, "too many triangles");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     free_triangles(c);
     if (n_tris == 0) return RT_OK;
     float *d_v = nullptr;
@@ -562,7 +604,7 @@ int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indic
     const int n_tris = n_indices / 3;
     if ((long long)n_tris * 8 >= (1ll << 31)) return fail(RT_E_LIMIT, "too many triangles");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     free_triangles(c);
     if (n_tris == 0) return RT_OK;
     if (n_verts == 0) return fail(RT_E_INVALID, "indices without vertices");
@@ -640,7 +682,7 @@ int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
     if (!tri_verts) return fail(RT_E_INVALID, "null vertex array");
     if (c->n_tris == 0 || n_tris != c->n_tris) return fail(RT_E_STATE, "triangle count does not match the loaded triangles");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     float *d_v = (float *)stage(c, sizeof(float) * 9 * (size_t)n_tris);
     if (!d_v) return fail(RT_E_NOMEM, "hipMalloc(vertices) failed");
     int rc = RT_OK;
@@ -660,7 +702,7 @@ int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
     if (!c->d_indices || c->n_tris == 0) return fail(RT_E_STATE, "no indexed mesh loaded (rt_set_mesh)");
     if (n_verts != c->n_mesh_verts) return fail(RT_E_STATE, "vertex count does not match the loaded mesh");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     // staging: the vertices, then one word for the index check of the set-up kernel
     const size_t vbytes = (sizeof(float) * 3 * (size_t)n_verts + 15) & ~(size_t)15;
     float *d_v = (float *)stage(c, vbytes + sizeof(int));
@@ -686,7 +728,7 @@ int rt_set_triangle_materials(rt_ctx *c, const rt_material *mats, int n_mats, co
     for (int k = 0; k < n_tris; k++)
         if (tri_material[k] < 0 || tri_material[k] >= n_mats) return fail(RT_E_INVALID, "material index out of range");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     std::vector<DevMaterial> hm((size_t)n_mats);
     for (int k = 0; k < n_mats; k++) hm[(size_t)k] = to_dev(&mats[k]);
     // tri_n.w carries the material index: patch it in place.
@@ -711,7 +753,7 @@ int rt_set_triangle_normals(rt_ctx *c, const float *corner_normals, int n_tris)
 {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     if (!corner_normals) {                      // back to the reference's geometric normals
         if (c->d_tri_vn) (void)hipFree(c->d_tri_vn);
         c->d_tri_vn = nullptr;
@@ -738,7 +780,7 @@ int rt_set_triangle_texcoords(rt_ctx *c, const float *corner_uv, int n_tris)
 {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    quiesce(c);
     if (!corner_uv) {
         if (c->d_tri_vt) (void)hipFree(c->d_tri_vt);
         c->d_tri_vt = nullptr;
@@ -866,7 +908,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->ms_build = c->bvh.ms_build;
     if (!c->frame_valid) return RT_OK;
     FrameCounters fc;
-    if (hipMemcpy(&fc, c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(&fc, c->last_counters ? c->last_counters : c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(RT_E_DEVICE, "read frame counters");
     if (fc.guard_hits)      // only a guarded build (-DRT_GUARD=1) ever counts these
         return fail(RT_E_DEVICE, "guarded build: " + std::to_string(fc.guard_hits) + " out-of-range indices were caught in the last frame");
@@ -889,7 +931,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->n_launches = c->last_launches;
     out->accel = c->last_accel;
     const int ne = c->ws.n_events;
-    if (c->opt_timing && ne >= 3 && (int)c->ws.events.size() >= ne) {
+    if (c->last_timed && ne >= 3 && (int)c->ws.events.size() >= ne) {
         // events: [start] [after each traversal stage] ... [after the final fold]
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)ne - 2]) == hipSuccess) out->ms_trace = ms;

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
     // would cost more than the whole linear scan of a small scene.
     const unsigned int wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (BLOCK / 64);
     const bool more = A.level < A.max_depth;
+    const int stack_cap = (A.stack_cap < STACK ? A.stack_cap : STACK) + 1;    // never past the LDS column, whatever the host passed
 
     for (unsigned int batch = wave_id; batch < A.n_batches; batch += n_waves) {
         const unsigned int cnt = PRIMARY ? 64u : A.counts_in[batch];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
         int best_id = -1;
         if (live) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
         if (ACCEL == 1) {
-            bvh_nearest<COUNT>(sc, o, d, live, best_t, best_id, stack, A.stack_cap + 1, tl);
+            bvh_nearest<COUNT>(sc, o, d, live, best_t, best_id, stack, stack_cap, tl);
         } else if (live) {
             brute_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
         }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             if (lit) occ = analytic_occluded<COUNT>(sc, so, L, tl);
             if (ACCEL == 1) {
                 bool go = lit && !occ;
-                if (bvh_occluded<COUNT>(sc, so, L, go, stack, A.stack_cap + 1, tl)) occ = true;
+                if (bvh_occluded<COUNT>(sc, so, L, go, stack, stack_cap, tl)) occ = true;
             } else if (lit && !occ) {
                 occ = brute_occluded<COUNT>(sc, so, L, tl);
             }

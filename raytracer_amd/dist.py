@@ -32,11 +32,36 @@ def deinterleave_numpy(gathered, H, band_rows):
     return out
 
 
-class PartitionedRenderer:
-    """Renders this rank's bands on its GPU and gathers the RGB8 slices with RCCL
-    (torch.distributed backend "nccl").  Buffers are allocated once."""
+def reduce_over_ranks(vec, dist=None):
+    """What a multi-rank measurement reports from one vector of per-rank numbers: (max over ranks,
+    sum over ranks), as two tensors like `vec`.  Times take the max (the frame is done when the last
+    rank is), ray counts the sum.  With dist None (one process) both are `vec` itself."""
+    if dist is None:
+        return vec, vec
+    mx = vec.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = vec.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    return mx, sm
 
-    def __init__(self, ctx, W, H, max_depth, rank=0, world=1, band_rows=DEFAULT_BAND_ROWS, device=None):
+
+class PartitionedRenderer:
+    """Renders this rank's bands and gathers the RGB8 slices with torch.distributed (backend "nccl",
+    which is RCCL, on GPUs).  Buffers are allocated once.
+
+    Stream order on a GPU: the library's render and de-interleave calls and the collective all run on
+    ONE stream owned by this object (a non-default torch stream, so its handle is never 0 — the ABI
+    reads a null stream as the context's private stream, which nothing else is ordered with).  render()
+    makes that stream wait for the caller's current stream first and the caller's current stream wait
+    for it last, so whoever consumes the returned tensor on the current stream sees the finished frame
+    without any device-wide synchronisation.
+
+    `render_rows(rowset, out)` and `deinterleave(gathered, frame)` are the two device operations; the
+    defaults call the context (rt_render_rows_device, rt_deinterleave_bands).  Passing other callables
+    (and a CPU device) runs the very same partition / gather / reassembly logic without a GPU."""
+
+    def __init__(self, ctx, W, H, max_depth, rank=0, world=1, band_rows=DEFAULT_BAND_ROWS, device=None,
+                 render_rows=None, deinterleave=None, dist=None):
         import torch
         self.torch = torch
         self.ctx, self.W, self.H, self.max_depth = ctx, W, H, max_depth
@@ -44,22 +69,52 @@ class PartitionedRenderer:
         self.rowset = band_rowset(H, band_rows, rank, world) if world > 1 else RowSet(0, 1, 1, H)
         self.cap_rows = rows_per_part(H, band_rows, world) if world > 1 else H
         dev = device if device is not None else torch.device("cuda", ctx.device)
-        self.local = torch.zeros((self.cap_rows, W, 3), dtype=torch.uint8, device=dev)
-        self.gathered = torch.empty((world * self.cap_rows, W, 3), dtype=torch.uint8, device=dev) if world > 1 else None
-        self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+        self.device = torch.device(dev)
+        self.on_gpu = self.device.type == "cuda"
+        if world > 1 and dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+        self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.local = torch.zeros((self.cap_rows, W, 3), dtype=torch.uint8, device=self.device)
+        self.gathered = torch.empty((world * self.cap_rows, W, 3), dtype=torch.uint8, device=self.device) if world > 1 else None
+        self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device) if (world > 1 and rank == 0) else None
+        self._render_rows = render_rows if render_rows is not None else self._ctx_render_rows
+        self._deinterleave = deinterleave if deinterleave is not None else self._ctx_deinterleave
 
-    def render(self):
-        """Enqueue one frame on torch's current stream; returns the tensor holding the full
-        frame on rank 0 (this rank's slice elsewhere)."""
-        torch = self.torch
-        stream = torch.cuda.current_stream().cuda_stream
-        self.ctx.render_rows_device(self.W, self.H, self.rowset, self.max_depth, d_rgb8=self.local.data_ptr(), stream=stream)
+    # ---- the default device operations (C ABI)
+    def _handle(self):
+        h = self.stream.cuda_stream
+        if not h:
+            raise RuntimeError("PartitionedRenderer needs a non-default stream")
+        return h
+
+    def _ctx_render_rows(self, rowset, out):
+        self.ctx.render_rows_device(self.W, self.H, rowset, self.max_depth, d_rgb8=out.data_ptr(), stream=self._handle())
+
+    def _ctx_deinterleave(self, gathered, frame):
+        self.ctx.deinterleave_bands(gathered.data_ptr(), frame.data_ptr(), self.W, self.H, self.band_rows, self.world,
+                                    self.cap_rows, 3, stream=self._handle())
+
+    def _frame(self):
+        self._render_rows(self.rowset, self.local)
         if self.world == 1:
             return self.local
-        import torch.distributed as dist
-        dist.all_gather_into_tensor(self.gathered, self.local)
+        # on a GPU the collective takes its order from the current stream (set by render() to self.stream)
+        self.dist.all_gather_into_tensor(self.gathered, self.local)
         if self.rank == 0:
-            self.ctx.deinterleave_bands(self.gathered.data_ptr(), self.frame.data_ptr(), self.W, self.H, self.band_rows,
-                                        self.world, self.cap_rows, 3, stream=stream)
+            self._deinterleave(self.gathered, self.frame)
             return self.frame
         return self.local
+
+    def render(self):
+        """Enqueue one frame; returns the tensor holding the full frame on rank 0 (this rank's
+        slice elsewhere), ordered on the caller's current stream."""
+        if not self.on_gpu:
+            return self._frame()
+        torch = self.torch
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)          # earlier readers/writers of our buffers on the caller's stream come first
+        with torch.cuda.stream(self.stream):
+            out = self._frame()
+        caller.wait_stream(self.stream)
+        return out

@@ -83,40 +83,101 @@ def test_soup_4m_triangles():
     assert_parity(compare(sub, rsub))
 
 
-def test_sponza_4k_in_eight_band_parts(sponza):
-    """The tile-partitioned 4K configuration on one GPU: the 3840x2160 frame rendered as the eight
-    16-row band sets the eight ranks would take, reassembled on the device, equals the frame rendered
-    whole; a pixel lattice of it equals the CPU oracle; the parts cast exactly the frame's rays."""
+def _band_parts_on_device(ctx, W, H, D, parts, band):
+    """Render the frame as the `parts` band sets the ranks of a `parts`-GPU job would take (16-row bands
+    round-robin, rt_rowset), each into its compact device buffer, and reassemble with rt_deinterleave_bands.
+    Returns (rgb8, hit_id, (primary, shadow, reflect) summed over the parts)."""
     import torch
+    cap = rt.rows_per_part(H, band, parts)
+    g8 = torch.zeros((parts, cap, W, 3), dtype=torch.uint8, device="cuda")
+    gid = torch.zeros((parts, cap, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    total = [0, 0, 0]
+    for p in range(parts):
+        ctx.render_rows_device(W, H, rt.band_rowset(H, band, p, parts), D, g8[p].data_ptr(), gid[p].data_ptr(), None, None, stream)
+        torch.cuda.synchronize()
+        total = [a + b for a, b in zip(total, rays(ctx.stats()))]
+    out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    outid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    ctx.deinterleave_bands(g8.data_ptr(), out8.data_ptr(), W, H, band, parts, cap, 3, stream)
+    ctx.deinterleave_bands(gid.data_ptr(), outid.data_ptr(), W, H, band, parts, cap, 4, stream)
+    torch.cuda.synchronize()
+    res = out8.cpu().numpy(), outid.cpu().numpy(), tuple(total)
+    del g8, gid, out8, outid
+    torch.cuda.empty_cache()
+    return res
+
+
+@pytest.fixture(scope="module")
+def sponza_4k(sponza):
+    """The 3840x2160 frame rendered whole (the module's context with the 4K camera), shared by the 2/4/8-part tests."""
     wl0, ctx = sponza
     wl = workloads.sponza(W=3840, H=2160)
-    W, H, D, parts, band = wl.W, wl.H, wl.max_depth, 8, 16
     wl.load(ctx)                                    # same scene, the 4K camera
     try:
-        whole = ctx.render_frame(W, H, max_depth=D, want=("rgb8", "hit_id"))
+        whole = ctx.render_frame(wl.W, wl.H, max_depth=wl.max_depth, want=("rgb8", "hit_id"))
         whole_rays = rays(ctx.stats())
-        cap = rt.rows_per_part(H, band, parts)
-        g8 = torch.zeros((parts, cap, W, 3), dtype=torch.uint8, device="cuda")
-        gid = torch.zeros((parts, cap, W), dtype=torch.int32, device="cuda")
-        stream = torch.cuda.current_stream().cuda_stream
-        total = [0, 0, 0]
-        for p in range(parts):
-            ctx.render_rows_device(W, H, rt.band_rowset(H, band, p, parts), D, g8[p].data_ptr(), gid[p].data_ptr(), None, None, stream)
-            torch.cuda.synchronize()
-            total = [a + b for a, b in zip(total, rays(ctx.stats()))]
-        out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
-        outid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-        ctx.deinterleave_bands(g8.data_ptr(), out8.data_ptr(), W, H, band, parts, cap, 3, stream)
-        ctx.deinterleave_bands(gid.data_ptr(), outid.data_ptr(), W, H, band, parts, cap, 4, stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(out8.cpu().numpy(), whole["rgb8"])
-        assert np.array_equal(outid.cpu().numpy(), whole["hit_id"])
-        assert tuple(total) == whole_rays
-        sc = O.scene_from_workload(wl, bvh=True)
-        lat = 6
-        r = sc.render(W, H, max_depth=D, cam=O.camera_from(wl.camera), use_bvh=True, threads=16, x_step=lat, y_step=lat)
-        assert np.array_equal(whole["hit_id"][::lat, ::lat], r["hit_id"][::lat, ::lat])
-        d = np.abs(whole["rgb8"][::lat, ::lat].astype(int) - r["rgb8"][::lat, ::lat].astype(int)).max(-1)
-        assert (d > 1).sum() == 0 and (d == 0).mean() >= 0.999
+        yield wl, ctx, whole, whole_rays
     finally:
         wl0.load(ctx)                               # leave the module's scene as the other tests expect it
+
+
+def test_sponza_4k_lattice_equals_cpu_oracle(sponza_4k):
+    wl, ctx, whole, whole_rays = sponza_4k
+    W, H, D = wl.W, wl.H, wl.max_depth
+    assert whole_rays[0] == W * H
+    sc = O.scene_from_workload(wl, bvh=True)
+    lat = 6
+    r = sc.render(W, H, max_depth=D, cam=O.camera_from(wl.camera), use_bvh=True, threads=16, x_step=lat, y_step=lat)
+    assert np.array_equal(whole["hit_id"][::lat, ::lat], r["hit_id"][::lat, ::lat])
+    d = np.abs(whole["rgb8"][::lat, ::lat].astype(int) - r["rgb8"][::lat, ::lat].astype(int)).max(-1)
+    assert (d > 1).sum() == 0 and (d == 0).mean() >= 0.999
+
+
+@pytest.mark.parametrize("parts", [2, 4, 8])
+def test_sponza_4k_in_band_parts(sponza_4k, parts):
+    """The tile-partitioned 4K configuration on one GPU: the 3840x2160 frame rendered as the 16-row band
+    sets that 2, 4 or 8 ranks would take, reassembled on the device, equals the frame rendered whole, and
+    the parts cast exactly the frame's rays."""
+    wl, ctx, whole, whole_rays = sponza_4k
+    rgb8, hid, total = _band_parts_on_device(ctx, wl.W, wl.H, wl.max_depth, parts, 16)
+    assert np.array_equal(rgb8, whole["rgb8"])
+    assert np.array_equal(hid, whole["hit_id"])
+    assert total == whole_rays
+
+
+def test_soup_4m_triangles_at_7680x4320_depth_8():
+    """The largest configuration at its stated size: 4.2 M triangles, 33 M pixels, 8 bounces.  Checked by
+    what does not depend on size: rendering twice gives the same bytes; the eight band parts reassemble to
+    the whole frame and cast exactly its rays; one primary ray per pixel; and a 48-pixel lattice of ids and
+    colours equals the CPU oracle's own BVH (every index in the frame's queues and planes is at its largest
+    here: 33 M slots per level, 9 levels)."""
+    wl = workloads.soup()
+    W, H, D = wl.W, wl.H, wl.max_depth
+    assert (W, H, D) == (7680, 4320, 8) and wl.n_tris > 4_000_000
+    with rt.Context(0) as ctx:
+        wl.load(ctx)
+        a = ctx.render_frame(W, H, max_depth=D, want=("rgb8", "hit_id"))
+        st = ctx.stats()
+        whole_rays = rays(st)
+        assert st["accel"] == 1 and st["n_triangles"] == wl.n_tris
+        assert whole_rays[0] == W * H
+        b = ctx.render_frame(W, H, max_depth=D, want=("rgb8", "hit_id"))
+        assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"])
+        del b
+        rgb8, hid, total = _band_parts_on_device(ctx, W, H, D, 8, 16)
+        assert np.array_equal(rgb8, a["rgb8"])
+        assert np.array_equal(hid, a["hit_id"])
+        assert total == whole_rays
+        del rgb8, hid
+    # casting rules at this size: every reflection ray and every shadow ray belongs to a hit
+    assert whole_rays[2] <= D * W * H and whole_rays[1] <= 2 * (whole_rays[0] + whole_rays[2])
+    sc = O.scene_from_workload(wl, bvh=True)
+    lat = 48
+    r = sc.render(W, H, max_depth=D, cam=O.camera_from(wl.camera), use_bvh=True, threads=16, x_step=lat, y_step=lat,
+                  want=("rgb8", "hit_id"))
+    n_lat = r["hit_id"][::lat, ::lat].size
+    assert n_lat >= 14_000
+    assert np.array_equal(a["hit_id"][::lat, ::lat], r["hit_id"][::lat, ::lat])
+    d = np.abs(a["rgb8"][::lat, ::lat].astype(int) - r["rgb8"][::lat, ::lat].astype(int)).max(-1)
+    assert (d > 1).sum() == 0 and (d == 0).mean() >= 0.999
