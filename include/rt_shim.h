@@ -197,6 +197,26 @@ int rt_render_frame_planes(rt_ctx *ctx, int W, int H, int y0, int y1, int max_de
 int rt_render_rows_device(rt_ctx *ctx, int W, int H, const rt_rowset *rows, int max_depth,
                           void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, void *stream);
 
+/* The same frame as rt_render_rows_device for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference, which allocates its one image with `new` (Raytracer/main.cpp:259) and nothing per ray.
+ * Calls no hipMalloc / hipFree and creates no events or graphs: the ray queues, per-level records and
+ * counters of the frame live in a static device array of RT_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends.  The frame runs as one kernel per bounce level (the
+ * pipeline RT_OPT_PIPELINE = 1 selects), whatever RT_OPT_PIPELINE says; outputs are bit-identical to
+ * rt_render_rows_device's.  Limits: RT_E_LIMIT when
+ *   256 + 16*(max_depth+1)*W*n_rows + 2*(32*Q + 4*(Q/64+1)) > RT_NOALLOC_SCRATCH_BYTES (each term rounded up
+ *   to 256 bytes), Q = W*n_rows padded to whole 8x8 pixel tiles, rounded up to a multiple of 256
+ * (800x600 at depth 3 and 512x512 at depth 4 fit; render a larger frame in row sets, one call each);
+ * RT_E_STATE when the mesh needs a hierarchy that is not built for the current options (it is built by
+ * rt_set_mesh / rt_set_triangles; options changed since take effect in rt_render_rows_device).
+ * All contexts on one GPU share that GPU's array: calls that overlap on one GPU race, so keep them on one
+ * stream or order them yourself.  RT_OPT_COUNT_TESTS and RT_OPT_TIMING do not apply (rt_get_stats reports
+ * ray counts, no times). */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_rows_device_noalloc(rt_ctx *ctx, int W, int H, const rt_rowset *rows, int max_depth,
+                                  void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, void *stream);
+
 /* Scatter a gathered set of compact band buffers back into a W x H image:
  * src holds n_parts consecutive parts, part k rendered with
  * {first_band=k, band_rows, band_stride=n_parts}, each padded to rows_per_part rows.

@@ -29,7 +29,9 @@ ABI_SYMBOLS = (
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
     "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals", "rt_set_triangle_texcoords",
+    "rt_render_rows_device_noalloc",
 )
+NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
 class RtError(RuntimeError):
@@ -171,6 +173,7 @@ def load_library():
     L.rt_render_frame.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.rt_render_frame_planes.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(FramePlanes)]
     L.rt_render_rows_device.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
+    L.rt_render_rows_device_noalloc.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
     L.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_synchronize.argtypes = [vp]
@@ -291,6 +294,12 @@ class Context:
         """rt_render_rows_device: raw device pointers (ints), asynchronous on `stream`."""
         self._check(self.L.rt_render_rows_device(self._h, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id, d_rgb32,
                                                  d_hit_t, stream))
+
+    def render_rows_device_noalloc(self, W, H, rowset, max_depth, d_rgb8=None, d_hit_id=None, d_rgb32=None, d_hit_t=None,
+                                   stream=None):
+        """rt_render_rows_device_noalloc: the same frame without any device allocation (static scratch, size-limited)."""
+        self._check(self.L.rt_render_rows_device_noalloc(self._h, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id,
+                                                         d_rgb32, d_hit_t, stream))
 
     def deinterleave_bands(self, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part, bytes_per_pixel, stream=None):
         self._check(self.L.rt_deinterleave_bands(self._h, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part,

@@ -9,7 +9,35 @@
 
 #include <new>
 
+#include <mutex>
+
+// Scratch of rt_render_rows_device_noalloc: one copy per GPU that loads this library, held until the process
+// ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress: the device address of a GPU's
+// copy is looked up once per device (scratch_for_device) and that pointer is what kernels and memsets receive.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int RT_MAX_DEVICES = 64;
+unsigned char *g_scratch_ptr[RT_MAX_DEVICES];     // [device ordinal] -> address of that device's `scratch`
+std::mutex g_scratch_mutex;
+
+// With `device` current: the address of this device's copy of the scratch array (looked up on first use).
+hipError_t scratch_for_device(int device, unsigned char **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned char *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 thread_local std::string g_err;
 
@@ -55,7 +83,8 @@ struct rt_ctx {
     bool last_wavefront = false;
     bool last_timed = false;                 // the last frame recorded its device events
     uint64_t last_primary = 0;
-    FrameCounters *last_counters = nullptr;  // where the last frame counted its rays
+    unsigned char *scratch_ptr = nullptr;    // this device's copy of the no-alloc scratch array (set by rt_create)
+    FrameCounters *last_counters = nullptr;  // where the last frame counted its rays (the workspace, or the scratch array)
     // Renders are asynchronous and may run on a caller's stream: frame_done is recorded behind every enqueued
     // frame, and everything that rewrites what a frame reads (scene, hierarchy, workspace, the captured graph)
     // waits for it first.
@@ -471,6 +500,16 @@ rt_ctx *rt_create(int device_ordinal)
         delete c;
         return nullptr;
     }
+    {
+        std::string err;
+        const hipError_t se = scratch_for_device(c->device, &c->scratch_ptr);
+        if (se != hipSuccess || device_num_cus(&err) <= 0) {
+            fail(RT_E_DEVICE, se != hipSuccess ? std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se) : err);
+            (void)hipStreamDestroy(c->stream);
+            delete c;
+            return nullptr;
+        }
+    }
     if (hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming) != hipSuccess) {
         fail(RT_E_DEVICE, "hipEventCreate failed");
         (void)hipStreamDestroy(c->stream);
@@ -863,6 +902,96 @@ int rt_render_rows_device(rt_ctx *c, int W, int H, const rt_rowset *rows, int ma
     DeviceGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return render_common(c, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, false);
+}
+
+// The frame of rt_render_rows_device through the one-kernel-per-bounce-level pipeline, with every intermediate
+// buffer (ray queues, per-level records, counters) carved out of this GPU's static scratch array: no hipMalloc,
+// no hipFree, no event or graph creation.  Calls that overlap on one GPU share the array and race.
+int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
+                                  void *d_rgb32, void *d_hit_t, void *stream)
+{
+    if (!c) return fail(RT_E_INVALID, "null context");
+    DeviceGuard g(c->device);
+    if (int rc = validate_rows(W, H, rows)) return rc;
+    if (max_depth < 0 || max_depth > RT_MAX_DEPTH) return fail(RT_E_INVALID, "max_depth out of range");
+    if (c->n_analytic == 0 && c->n_tris == 0) return fail(RT_E_STATE, "no scene set");
+    if (!c->scratch_ptr) return fail(RT_E_STATE, "no scratch array on this device");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->frame_valid = false;
+    const size_t pixels = (size_t)W * (size_t)rows->n_rows;
+    if (pixels == 0) return RT_OK;
+    // the hierarchy is built when the mesh is set; building it here would allocate
+    bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
+    if (c->n_tris < 2) want = false;
+    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder))
+        return fail(RT_E_STATE, "the hierarchy for the current options is not built: set the mesh after the options, or render once "
+                                "through rt_render_rows_device");
+    const int accel = want ? 1 : 0;
+
+    // ---- carve the scratch array: counters | records[levels][pixels] | 2 x (origins, directions)[qslots] | 2 x batch counts
+    const size_t slots = (size_t)((W + 7) / 8) * (size_t)((rows->n_rows + 7) / 8) * 64;
+    const size_t qslots = wavefront_regions(slots > pixels ? slots : pixels) * 256;
+    const size_t levels = (size_t)max_depth + 1;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += up(bytes); return at; };
+    const size_t o_counters = take(sizeof(FrameCounters));
+    const size_t o_records = take(sizeof(float4) * pixels * levels);
+    size_t o_qo[2], o_qd[2], o_fq[2];
+    for (int k = 0; k < 2; k++) {
+        o_qo[k] = take(sizeof(float4) * qslots);
+        o_qd[k] = take(sizeof(float4) * qslots);
+        o_fq[k] = take(sizeof(unsigned int) * (qslots / 64 + 1));
+    }
+    if (off > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+        return fail(RT_E_LIMIT, "frame needs " + std::to_string(off) + " bytes of scratch (" + std::to_string(pixels) + " pixels x " +
+                                    std::to_string(levels) + " levels); rt_render_rows_device_noalloc holds " +
+                                    std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES) + ": render fewer rows per call or use rt_render_rows_device");
+    unsigned char *base = c->scratch_ptr;
+    FrameWorkspace ws;
+    ws.counters = (FrameCounters *)(base + o_counters);
+    ws.records = (float4 *)(base + o_records);
+    for (int k = 0; k < 2; k++) {
+        ws.queue_o[k] = (float4 *)(base + o_qo[k]);
+        ws.queue_d[k] = (float4 *)(base + o_qd[k]);
+        ws.fq_counts[k] = (unsigned int *)(base + o_fq[k]);
+    }
+    ws.pixels_cap = qslots;
+    ws.levels_cap = (int)levels;
+
+    const DevScene sc = device_scene(c, accel);
+    FrameParams fp;
+    fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
+    fp.count_tests = 0; fp.timing = 0;             // counting builds and device events are the allocating entry point's
+    fp.stack_depth = accel ? c->bvh.depth : 0;
+    fp.wide_depth = accel ? c->bvh.wide_depth : 0;
+    fp.pipeline = 1;                               // one fused kernel per bounce level: its whole workspace is the carve above
+    fp.d_normal = nullptr; fp.d_uv = nullptr;
+    // the array keeps the last call's bytes: the counters are cleared by trace_frame's memset, every batch count
+    // and every record a level reads was written by the level before it in this same frame
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && c->frame_pending && s != c->last_stream && hipStreamWaitEvent(s, c->frame_done, 0) != hipSuccess)
+        return fail(RT_E_DEVICE, "hipStreamWaitEvent failed");
+    std::string err;
+    int launches = 0;
+    const int rc = trace_frame(sc, c->cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, &launches, &err);
+    if (rc != RT_OK) return fail(rc, err);
+    if (!capturing) {
+        if (hipEventRecord(c->frame_done, s) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
+        c->frame_pending = true;
+        c->last_stream = s;
+    }
+    c->last_counters = ws.counters;
+    c->last_timed = false;
+    c->frame_valid = true;
+    c->last_levels = max_depth + 1;
+    c->last_launches = launches;
+    c->last_accel = accel;
+    c->last_wavefront = false;
+    c->last_primary = pixels;
+    return RT_OK;
 }
 
 int rt_deinterleave_bands(rt_ctx *c, const void *d_src, void *d_dst, int W, int H, int band_rows, int n_parts,
