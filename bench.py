@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "cube", "soup"])
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "cube", "soup", "atrium2"])
+    ap.add_argument("--obj", default="", help="an OBJ file to render in place of the Sponza stand-in (default: $RT_SPONZA_OBJ when it exists)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the share table, the eager loop and the second stand-in (N = 1 extras)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--depth", type=int, default=-1)
@@ -79,6 +81,49 @@ def cpu_baseline(wl, threads):
     return out
 
 
+def timed_frames(render, sync, steps, warmup):
+    for _ in range(warmup):
+        render()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render()
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def share_table(ctx, wl, band_rows, torch, dev, steps=10):
+    """One rank's share of the frame, measured on this GPU: part 0 of 1, 2, 4 and 8 parts (16-row bands
+    round-robin), graph replay, RGB8 only, ms per frame.  What strong scaling can reach before the gather."""
+    import raytracer_amd as rt
+    out = {}
+    buf = torch.zeros((wl.H, wl.W, 3), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    for parts in (1, 2, 4, 8):
+        rs = rt.band_rowset(wl.H, band_rows, 0, parts) if parts > 1 else rt.RowSet(0, 1, 1, wl.H)
+        render = lambda: ctx.render_rows_device(wl.W, wl.H, rs, wl.max_depth, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+        out[str(parts)] = timed_frames(render, torch.cuda.synchronize, steps, 3)
+    return out
+
+
+def measured_traffic(workload, world):
+    """HBM-side bytes per frame of the traversal kernel from the committed counter passes
+    (profiles/hbm_traffic.json, written by profiles/hbm_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
+    runs).  Counters cannot be read inside this process, so the figure is only reported when the file was
+    measured on exactly these kernel sources (its source_hash equals the tree's); otherwise null."""
+    from raytracer_amd.build import source_hash
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception:
+        return None, "none"
+    if rec.get("source_hash") != source_hash():
+        return None, "profiles/hbm_traffic.json is stale (measured on other kernel sources)"
+    if world != 1 or workload not in rec:
+        return None, "profiles/hbm_traffic.json has no entry for this run"
+    return rec[workload].get("bytes_per_frame"), "profiles/hbm_traffic.json (" + rec[workload].get("source", "") + ")"
+
+
 def main():
     a = parse()
     if a.lib:
@@ -86,7 +131,7 @@ def main():
     import torch
     import raytracer_amd as rt
     from raytracer_amd import workloads
-    from raytracer_amd.dist import PartitionedRenderer
+    from raytracer_amd.dist import PartitionedRenderer, reduce_over_ranks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,6 +153,10 @@ def main():
     if a.width: kw["W"] = a.width
     if a.height: kw["H"] = a.height
     if a.depth >= 0: kw["max_depth"] = a.depth
+    if a.obj:
+        kw["obj"] = a.obj
+        if a.workload != "sponza" or not os.path.exists(a.obj):
+            raise SystemExit("--obj needs an existing file and the sponza workload")
     wl = workloads.by_name(a.workload, **kw)
 
     ctx = rt.Context(local_rank)
@@ -147,17 +196,10 @@ def main():
     rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
     vec = torch.tensor([dt, float(rays_local), float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"]),
                         st["ms_trace"], st["ms_frame"]], dtype=torch.float64, device=dev)
-    if dist is not None:
-        mx = vec.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = vec.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt = float(mx[0])
-        rays = float(sm[1]); rp, rs, rr = float(sm[2]), float(sm[3]), float(sm[4])
-        ms_trace, ms_frame = float(mx[5]), float(mx[6])
-    else:
-        rays = float(rays_local); rp, rs, rr = float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"])
-        ms_trace, ms_frame = st["ms_trace"], st["ms_frame"]
+    mx, sm = reduce_over_ranks(vec, dist)        # times: max over ranks; ray counts: sum over ranks
+    dt = float(mx[0])
+    rays = float(sm[1]); rp, rs, rr = float(sm[2]), float(sm[3]), float(sm[4])
+    ms_trace, ms_frame = float(mx[5]), float(mx[6])
 
     # ---- roofline of the dominant kernel (k_bounce, all levels of one frame), rank 0's share:
     # algorithmic flops from a counting pass outside the timed region, duration from the
@@ -170,20 +212,14 @@ def main():
     # k_trace (LBVH scenes: traversal alone, timed by its own device events) or k_bounce (small scenes)
     kernel_ms = st["ms_traverse"] if st["ms_traverse"] > 0 else st["ms_trace"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(a.workload if world == 1 else "", {}).get("bytes_per_frame")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = measured_traffic(a.workload, world)
     compulsory = wl.W * wl.H * 3 + wl.n_tris * (48 + 16) + st["bvh_nodes"] * 64
     roofline = {
         "bound": "valu_fp32",
         "kernel": ("k_trace (closest + any-hit, all %d levels of one frame)" if st["accel"] else
                    "k_bounce (all %d levels of one frame)") % (wl.max_depth + 1),
         "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_source,
         "flops_per_frame": flops, "box_tests": cst["box_tests"], "tri_tests": cst["tri_tests"],
         "analytic_tests": cst["analytic_tests"], "kernel_ms_per_frame": kernel_ms,
         "all_bounce_stages_ms_per_frame": st["ms_trace"],
@@ -204,6 +240,28 @@ def main():
             "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
             "roofline": roofline,
         }
+        if world == 1 and not a.no_extras:
+            # the same frames with every launch issued one by one (a frame that changes cannot replay a graph)
+            ctx.set_option(rt.OPT_TIMING, 0)
+            ctx.set_option(rt.OPT_GRAPH, 0)
+            out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
+            ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
+            if st["accel"]:
+                out["share_ms"] = share_table(ctx, wl, a.band_rows, torch, dev)
+            if a.workload == "sponza":
+                # the second stand-in (irregular triangle sizes, slivers, overlapping cloth) through the same loop
+                wl2 = workloads.atrium2(W=wl.W, H=wl.H, max_depth=wl.max_depth)
+                with rt.Context(local_rank) as ctx2:
+                    wl2.load(ctx2)
+                    ctx2.set_option(rt.OPT_TIMING, 0)
+                    pr2 = PartitionedRenderer(ctx2, wl2.W, wl2.H, wl2.max_depth, 0, 1, a.band_rows, dev)
+                    ms2 = timed_frames(pr2.render, sync_all, a.steps, a.warmup)
+                    ctx2.set_option(rt.OPT_TIMING, 1)
+                    pr2.render(); sync_all()
+                    s2 = ctx2.stats()
+                r2 = s2["rays_primary"] + s2["rays_shadow"] + s2["rays_reflect"]
+                out["other_workloads"] = {wl2.name: {"value": r2 / ms2 / 1e3, "unit": "Mrays/s", "ms_per_step": ms2,
+                                                     "rays_per_frame": r2, "triangles": wl2.n_tris, "lbvh_build_ms": s2["ms_build"]}}
         if world == 1 and not a.no_cpu_baseline:
             threads = a.cpu_threads or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(wl, threads)

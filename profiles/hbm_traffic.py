@@ -3,7 +3,10 @@ from the FETCH_SIZE / WRITE_SIZE passes of a profiles/collect.sh summary (counte
 FETCH_SIZE is doubled: on gfx950 it tallies 128-byte requests at 64 bytes (calibrated on wide
 streaming reads; the traversal's 16-32 byte gathers are uncalibrated, so treat the figure as
 an estimate).  Only the non-counting k_trace variants (<..., false>) are summed."""
-import json, re, sys
+import json, os, re, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from raytracer_amd.build import source_hash
 
 def main(path, frames, workload="sponza"):
     fetch = write = 0.0
@@ -16,7 +19,8 @@ def main(path, frames, workload="sponza"):
             if c == "FETCH_SIZE": fetch += float(v) * n
             if c == "WRITE_SIZE": write += float(v) * n
     per_frame = (2.0 * fetch + write) * 1024.0 / frames
-    out = {workload: {"bytes_per_frame": per_frame, "fetch_KiB_raw_per_frame": fetch / frames, "write_KiB_per_frame": write / frames,
+    out = {"source_hash": source_hash(),
+           workload: {"bytes_per_frame": per_frame, "fetch_KiB_raw_per_frame": fetch / frames, "write_KiB_per_frame": write / frames,
                       "kernel": "k_trace, all launches of one frame", "source": path.split("/")[-1],
                       "note": "FETCH_SIZE x2 (gfx950 request-size correction) + WRITE_SIZE; includes Infinity-Cache hits"}}
     print(json.dumps(out, indent=1))

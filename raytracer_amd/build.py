@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "librt_amd.so")
 HOST_BIN = os.path.join(HERE, "bin", "raytracer")
+OBJHOST_LIB = os.path.join(HERE, "libobjhost.so")
+GUARD_LIB = os.path.join(HERE, "variants", "guard.so")
 
 HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "persistent.hip", "lbvh.hip"]
 HIP_FLAGS = [
@@ -38,20 +40,58 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build_lib(force=False, verbose=False, extra_flags=()):
+def _lib_deps():
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "rt_internal.h"), os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_traverse.h"), os.path.join(ROOT, "include", "rt_shim.h"), __file__]
-    if not force and not extra_flags and _newer(LIB, deps):
-        return LIB
-    cmd = [_hipcc()] + HIP_FLAGS + list(extra_flags) + srcs + ["-o", LIB]
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    return srcs, srcs + hdrs + [os.path.join(ROOT, "include", "rt_shim.h"), __file__]
+
+
+def source_hash():
+    """sha256 over the device sources the library is built from: the key that ties a committed counter
+    measurement (profiles/hbm_traffic.json) to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_lib_deps()[1]):
+        if path.endswith((".hip", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_lib(force=False, verbose=False, extra_flags=(), out=LIB):
+    srcs, deps = _lib_deps()
+    if not force and _newer(out, deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [_hipcc()] + HIP_FLAGS + list(extra_flags) + srcs + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
+
+
+def build_guard(force=False, verbose=False):
+    """The guarded variant (-DRT_GUARD=1: every index that comes out of device data is checked against its
+    array before use).  Built with the library so that it cannot rot; kernel changes are tried on it first
+    (pytest --rt-lib raytracer_amd/variants/guard.so, bench.py --lib ...)."""
+    return build_lib(force=force, verbose=verbose, extra_flags=("-DRT_GUARD=1",), out=GUARD_LIB)
+
+
+def build_objhost(force=False, verbose=False):
+    """libobjhost.so: include/rt_objhost.h, the host's OBJ loader behind a C ABI (no GPU code)."""
+    srcs = [os.path.join(HOST, "objhost_c.cpp"), os.path.join(HOST, "objloader.cpp")]
+    deps = srcs + [os.path.join(HOST, "objloader.h"), os.path.join(HOST, "maths.h"), os.path.join(ROOT, "include", "rt_objhost.h")]
+    if not force and _newer(OBJHOST_LIB, deps):
+        return OBJHOST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared"] + srcs + ["-o", OBJHOST_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return OBJHOST_LIB
 
 
 def build_host(force=False, verbose=False):
-    srcs = [os.path.join(HOST, s) for s in sorted(os.listdir(HOST)) if s.endswith(".cpp")] if os.path.isdir(HOST) else []
+    srcs = [os.path.join(HOST, s) for s in sorted(os.listdir(HOST)) if s.endswith(".cpp") and s != "objhost_c.cpp"] if os.path.isdir(HOST) else []
     if not srcs:
         return None
     hdrs = [os.path.join(HOST, s) for s in os.listdir(HOST) if s.endswith(".h")]
@@ -68,7 +108,9 @@ def build_host(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     build_lib(force=force, verbose=verbose)
+    build_guard(force=force, verbose=verbose)
     build_host(force=force, verbose=verbose)
+    build_objhost(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

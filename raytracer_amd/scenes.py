@@ -154,6 +154,55 @@ def atrium_mesh(detail=1.0, seed=0):
     return B.result()
 
 
+def atrium2_mesh(seed=0):
+    """The courtyard again, built the way a modelled asset is rather than as even grids (about 270k triangles):
+    floor, walls and gallery slabs are single quads of two huge triangles; columns are 64 flutes of one
+    full-height quad each (slivers of aspect > 100:1); thin rails run the length of the galleries and
+    diagonal wires cross the courtyard (long, thin and not axis-aligned); next to them sit ornaments of
+    ~50k triangles inside half a unit, dense capitals, and cloths hanging in three overlapping layers a
+    few centimetres apart.  Same footprint, camera and lights as atrium_mesh().
+    Returns (verts[n,3] f32, indices[3m] i32, tri_material[m] i32)."""
+    B = _Builder(seed)
+    x_col, x_wall, z_front, z_back = 3.2, 7.0, -4.0, 18.0
+    y_floor, y_cap, y_gallery, y_top = -4.0, 1.0, 3.4, 7.0
+    # two-triangle floor and walls
+    B.patch((-x_wall, y_floor, z_front), (0, 0, z_back - z_front), (2 * x_wall, 0, 0), 1, 1, 1)
+    B.patch((-x_wall, y_floor, z_front), (0, y_top - y_floor, 0), (0, 0, z_back - z_front), 1, 1, 0)
+    B.patch((x_wall, y_floor, z_front), (0, 0, z_back - z_front), (0, y_top - y_floor, 0), 1, 1, 0)
+    B.patch((-x_wall, y_floor, z_back), (2 * x_wall, 0, 0), (0, y_top - y_floor, 0), 1, 1, 0)
+    zs = np.arange(0.0, 16.1, 4.0)
+    for side in (-1.0, 1.0):
+        x = side * x_col
+        for z in zs:
+            B.column(x, z, y_floor, y_cap, 0.38, 64, 1, 0)                    # full-height slivers
+            B.ball((x, y_cap + 0.25, z), 0.42, 72, 36, 4)                      # dense capital
+        for z0, z1 in zip(zs[:-1], zs[1:]):
+            B.arch(x, z0, z1, y_cap + 0.45, 0.22, 72, 28, 0)
+        xa, xb = (x, side * x_wall) if side > 0 else (side * x_wall, x)
+        B.patch((xa, y_gallery, zs[0] - 1), (0, 0, zs[-1] - zs[0] + 2), (xb - xa, 0, 0), 1, 1, 0)
+        B.patch((xa, y_gallery - 0.3, zs[0] - 1), (xb - xa, 0, 0), (0, 0, zs[-1] - zs[0] + 2), 1, 1, 0)
+        B.patch((x, y_gallery - 0.3, zs[0] - 1), (0, 0.3, 0), (0, 0, zs[-1] - zs[0] + 2), 1, 1, 0)
+        # rails: 18 m long, 2 cm wide
+        for j in range(10):
+            B.patch((x - side * 0.1, y_gallery + 0.1 * (j + 1), zs[0] - 1), (0, 0, zs[-1] - zs[0] + 2), (0, 0.02, 0), 1, 1, 4)
+        # three overlapping cloth layers per bay
+        for j, (z0, z1) in enumerate(zip(zs[:-1], zs[1:])):
+            for layer in range(3):
+                B.curtain(x - side * (0.05 + 0.03 * layer), z0 + 0.6 - 0.1 * layer, z1 - 0.6 + 0.1 * layer, y_cap - 1.5 + 0.2 * layer,
+                          y_gallery - 0.3, 60, 30, 2 + ((j + layer) & 1), depth=0.25 - 0.05 * layer, waves=7 - layer)
+    # wires across the courtyard, gallery edge to gallery edge, none parallel to an axis
+    for j in range(24):
+        za, zb = -1.0 + 0.75 * j, 17.0 - 0.75 * j
+        B.patch((-x_col, y_gallery + 0.2, za), (2 * x_col, 0.5 + 0.05 * j, zb - za), (0, 0.015, 0), 1, 1, 4)
+    # two ornaments of ~50k triangles each, on pedestals of two-triangle faces
+    for cx in (-1.6, 1.6):
+        B.ball((cx, y_floor + 1.3, 3.0), 0.5, 224, 112, 4)
+        for dx_, dz_, nx_, nz_ in ((-0.4, -0.4, 0.8, 0.0), (0.4, -0.4, 0.0, 0.8), (0.4, 0.4, -0.8, 0.0), (-0.4, 0.4, 0.0, -0.8)):
+            B.patch((cx + dx_, y_floor, 3.0 + dz_), (0, 0.8, 0), (nx_, 0, nz_), 1, 1, 0)
+        B.patch((cx - 0.4, y_floor + 0.8, 2.6), (0, 0, 0.8), (0.8, 0, 0), 1, 1, 0)
+    return B.result()
+
+
 def instance_grid(verts, indices, tri_mat, nx, nz, dx, dz):
     """nx x nz translated copies (the instanced 'soup'); instance (i,j) is shifted by (i*dx, 0, j*dz)."""
     V, I, M = [], [], []

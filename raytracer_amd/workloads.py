@@ -10,6 +10,9 @@ Each workload is the reference's stock lights (Raytracer/main.cpp:245-253) plus 
 Mesh triangles get reflect = 0.5 (the reference gives meshes reflect = 0, main.cpp:34 + 230,
 so bounces on meshes need this declared material extension).
 """
+import ctypes as C
+import os
+
 import numpy as np
 
 from . import Camera, Material, Plane, Sphere, camera_for_width, scenes
@@ -68,10 +71,79 @@ def cube(W=1920, H=1080, max_depth=4, reflect=0.5):
                     [Material(reflect=reflect)], np.zeros(len(i) // 3, np.int32), W, H, max_depth, camera_for_width(W))
 
 
-def sponza(W=1920, H=1080, max_depth=4, detail=ATRIUM_DETAIL):
+def load_obj(path, relaxed=True):
+    """An OBJ file through the host's own loader (include/rt_objhost.h over raytracer_amd/host/objloader.cpp,
+    the restatement of Raytracer/objloader.cpp:18-105).  Returns verts (n,3) f32, indices (3m) i32,
+    tri_material (m) i32, materials (k,6) f32 = (reflect, diffuse, spec, r, g, b), dropped face count."""
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libobjhost.so")
+    if not os.path.exists(lib_path):
+        raise RuntimeError("%s not built: run `python raytracer_amd/build.py`" % lib_path)
+    L = C.CDLL(lib_path)
+    L.rt_obj_load.restype = C.c_void_p
+    L.rt_obj_load.argtypes = [C.c_char_p, C.c_int]
+    L.rt_obj_free.argtypes = [C.c_void_p]
+    L.rt_obj_counts.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_obj_copy.argtypes = [C.c_void_p] * 5
+    h = L.rt_obj_load(os.fsencode(path), 1 if relaxed else 0)
+    if not h:
+        raise MemoryError("rt_obj_load")
+    try:
+        cnt = np.zeros(4, np.int32)
+        L.rt_obj_counts(h, cnt.ctypes.data)
+        nv, ni, nm, dropped = (int(x) for x in cnt)
+        v = np.zeros((nv, 3), np.float32); i = np.zeros(ni, np.int32)
+        tm = np.zeros(ni // 3, np.int32); mats = np.zeros((nm, 6), np.float32)
+        L.rt_obj_copy(h, v.ctypes.data, i.ctypes.data, tm.ctypes.data, mats.ctypes.data)
+    finally:
+        L.rt_obj_free(h)
+    return v, i, tm, mats, dropped
+
+
+def fit_to_courtyard(verts):
+    """Place an arbitrary mesh where the courtyard camera and the reference lights (main.cpp:245-253) expect the
+    atrium: the longer horizontal axis becomes z, the mesh is scaled uniformly so that axis spans 22 units
+    (z in [-4, 18]), centred in x, floor at y = -4.  Rotation by a quarter turn about y keeps the handedness."""
+    v = np.asarray(verts, np.float64).copy()
+    lo, hi = v.min(0), v.max(0)
+    if (hi[0] - lo[0]) > (hi[2] - lo[2]):
+        v = np.stack([-v[:, 2], v[:, 1], v[:, 0]], 1)
+        lo, hi = v.min(0), v.max(0)
+    scale = 22.0 / max(hi[2] - lo[2], 1e-30)
+    v = (v - np.array([0.5 * (lo[0] + hi[0]), lo[1], lo[2]])) * scale + np.array([0.0, -4.0, -4.0])
+    return v.astype(np.float32)
+
+
+def sponza_obj(path, W=1920, H=1080, max_depth=4, reflect=0.5):
+    """The mesh of main.cpp:257 (`LoadModel(".../sponza.obj")`) from a supplied file, fitted to the courtyard
+    camera.  The reference gives mesh triangles reflect = 0 (main.cpp:34 + 230), so bounces need a declared
+    material extension: materials of a .mtl that set a reflection coefficient keep it, every other material
+    gets `reflect` (the stand-in's 0.5)."""
+    v, i, tm, mats, dropped = load_obj(path, relaxed=True)
+    if len(i) < 3:
+        raise RuntimeError("%s holds no triangles" % path)
+    ms = [Material(float(m[0]) if m[0] > 0 else reflect, float(m[1]), float(m[2]), tuple(float(c) for c in m[3:6])) for m in mats]
+    name = "%s(%d tris) %dx%d depth %d" % (os.path.basename(path), len(i) // 3, W, H, max_depth)
+    return Workload(name, [_mirror()] + _lights(), fit_to_courtyard(v), i, ms, tm, W, H, max_depth, _courtyard_camera(W))
+
+
+def sponza(W=1920, H=1080, max_depth=4, detail=ATRIUM_DETAIL, obj=None):
+    """sponza.obj when a file is supplied (argument, else the RT_SPONZA_OBJ environment variable) and exists;
+    otherwise the procedural stand-in: the asset is not part of the reference tree."""
+    obj = obj or os.environ.get("RT_SPONZA_OBJ", "")
+    if obj and os.path.exists(obj):
+        return sponza_obj(obj, W, H, max_depth)
     v, i, m = scenes.atrium_mesh(detail=detail)
     mats = [Material(*t) for t in _ATRIUM_MATS]
     return Workload("sponza-standin(atrium %d tris) %dx%d depth %d" % (len(i) // 3, W, H, max_depth),
+                    [_mirror()] + _lights(), v, i, mats, m, W, H, max_depth, _courtyard_camera(W))
+
+
+def atrium2(W=1920, H=1080, max_depth=4):
+    """A second stand-in with the irregularities of the real asset (scenes.atrium2_mesh): two-triangle walls
+    next to dense ornaments, long thin slivers, overlapping cloth."""
+    v, i, m = scenes.atrium2_mesh()
+    mats = [Material(*t) for t in _ATRIUM_MATS]
+    return Workload("sponza-standin-v2(atrium2 %d tris) %dx%d depth %d" % (len(i) // 3, W, H, max_depth),
                     [_mirror()] + _lights(), v, i, mats, m, W, H, max_depth, _courtyard_camera(W))
 
 
@@ -85,4 +157,4 @@ def soup(W=7680, H=4320, max_depth=8, detail=ATRIUM_DETAIL, nx=4, nz=4):
 
 
 def by_name(name, **kw):
-    return {"cube": cube, "sponza": sponza, "soup": soup}[name](**kw)
+    return {"cube": cube, "sponza": sponza, "soup": soup, "atrium2": atrium2}[name](**kw)

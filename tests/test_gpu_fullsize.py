@@ -64,6 +64,31 @@ def test_sponza_1080p_properties(sponza):
     assert sz["rays_shadow"] <= s1["rays_shadow"] <= sa["rays_shadow"] and s1["rays_reflect"] <= sa["rays_reflect"]
 
 
+@pytest.mark.parametrize("builder", [rt.BUILDER_PLOC, rt.BUILDER_LBVH])
+def test_second_stand_in_1080p_equals_cpu_oracle_and_linear_scan_lattice(builder):
+    """The irregular stand-in (two-triangle walls beside 50k-triangle ornaments, slivers, overlapping cloth): the
+    full 1080p frame against the oracle's own BVH, and a lattice against the oracle's brute-force scan (the
+    reference's algorithm, main.cpp:149-156), for both hierarchy builders."""
+    wl = workloads.atrium2()
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_BUILDER, builder)
+        wl.load(ctx)
+        g = ctx.render_frame(wl.W, wl.H, max_depth=wl.max_depth)
+        st = ctx.stats()
+    assert st["accel"] == 1 and st["n_triangles"] == wl.n_tris and st["bvh_depth"] <= 64
+    sc = O.scene_from_workload(wl, bvh=True)
+    cam = O.camera_from(wl.camera)
+    r = sc.render(wl.W, wl.H, max_depth=wl.max_depth, cam=cam, use_bvh=True, threads=16)
+    assert_parity(compare(g, r))
+    assert rays(st) == orays(r)
+    if builder == rt.BUILDER_PLOC:
+        lat = 96
+        b = sc.render(wl.W, wl.H, max_depth=wl.max_depth, cam=cam, use_bvh=False, threads=16, x_step=lat, y_step=lat)
+        sub = {k: g[k][::lat, ::lat] for k in ("rgb8", "rgb32", "hit_id")}
+        bsub = {k: b[k][::lat, ::lat] for k in ("rgb8", "rgb32", "hit_id")}
+        assert_parity(compare(sub, bsub))
+
+
 def test_soup_4m_triangles():
     wl = workloads.soup(W=1280, H=720, max_depth=8)
     assert wl.n_tris > 4_000_000

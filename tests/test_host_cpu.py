@@ -213,3 +213,87 @@ def test_relaxed_loader_keeps_the_normal_and_texcoord_index_of_every_corner():
     assert pairs == [(0, 0), (1, 1), (0, 0),  (0, 0), (0, 0), (1, 1),
                      (1, -1), (0, -1), (2, -1),
                      (-1, 1), (-1, -1), (-1, -1)]
+
+
+# ------------------------------------------------------------------ OBJ loader behind its C ABI, bench workloads
+def test_objhost_library_exports_every_declared_symbol_and_loads_a_mesh(tmp_path):
+    from raytracer_amd import workloads
+    header = open(os.path.join(ROOT, "include", "rt_objhost.h")).read()
+    declared = set(re.findall(r"\b(rt_obj_[a-z_]+)\s*\(", header))
+    L = ctypes.CDLL(os.path.join(ROOT, "raytracer_amd", "libobjhost.so"))
+    assert declared == {"rt_obj_load", "rt_obj_free", "rt_obj_counts", "rt_obj_copy"}
+    for s in declared:
+        assert hasattr(L, s), s
+    v, q = scenes.cube_quads()
+    path = str(tmp_path / "cube_quads.obj")
+    scenes.write_obj(path, v, q)
+    for relaxed in (False, True):
+        lv, li, tm, mats, dropped = workloads.load_obj(path, relaxed=relaxed)
+        assert dropped == 0 and np.array_equal(lv, v) and np.array_equal(li, scenes.cube_mesh()[1])    # quads fan-split, objloader.cpp:90-99
+        assert len(tm) == 12 and mats.shape == (1, 6) and tuple(mats[0]) == (0.0, 1.0, 1.0, 1.0, 1.0, 1.0)   # Material(), main.cpp:34
+    # a missing file is an empty mesh (objloader.cpp:22,104), not an error
+    lv, li, tm, mats, dropped = workloads.load_obj(str(tmp_path / "absent.obj"))
+    assert len(lv) == 0 and len(li) == 0
+
+
+def test_sponza_workload_takes_a_supplied_obj_and_falls_back_to_the_stand_in(tmp_path, monkeypatch):
+    from raytracer_amd import workloads
+    v, i, m = scenes.atrium_mesh(detail=0.002)
+    # a mesh lying along x, in other units: it must come out along z inside the courtyard box
+    big = np.stack([v[:, 2] * 100.0, v[:, 1] * 100.0 + 3.0, v[:, 0] * 100.0], 1)
+    path = str(tmp_path / "sponza.obj")
+    scenes.write_obj(path, big, i.reshape(-1, 3))
+    wl = workloads.sponza(W=64, H=36, obj=path)
+    assert wl.name.startswith("sponza.obj(") and wl.n_tris == len(i) // 3
+    lo, hi = wl.verts.min(0), wl.verts.max(0)
+    assert abs(lo[1] + 4.0) < 1e-4 and abs(lo[2] + 4.0) < 1e-4 and abs(hi[2] - 18.0) < 1e-3 and abs(lo[0] + hi[0]) < 1e-3
+    assert all(mm.reflect == 0.5 for mm in wl.mats)           # no .mtl: the declared mesh-reflection extension
+    monkeypatch.setenv("RT_SPONZA_OBJ", path)
+    assert workloads.sponza(W=64, H=36).name.startswith("sponza.obj(")
+    monkeypatch.setenv("RT_SPONZA_OBJ", str(tmp_path / "nothing.obj"))
+    assert workloads.sponza(W=64, H=36, detail=0.002).name.startswith("sponza-standin(")
+
+
+def test_second_stand_in_has_the_irregularities_it_is_for():
+    v, i, m = scenes.atrium2_mesh()
+    assert 250_000 < len(i) // 3 < 300_000
+    t = v[i.reshape(-1, 3)].astype(np.float64)
+    e = np.stack([np.linalg.norm(t[:, 1] - t[:, 0], axis=1), np.linalg.norm(t[:, 2] - t[:, 1], axis=1),
+                  np.linalg.norm(t[:, 0] - t[:, 2], axis=1)], 1)
+    area = 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1)
+    assert ((e.max(1) ** 2 / (2 * area + 1e-30)) > 100).sum() > 1000        # slivers of aspect > 100:1
+    assert area.max() / np.median(area) > 1e5                                # two-triangle walls beside dense ornaments
+    v2, i2, m2 = scenes.atrium2_mesh()
+    assert np.array_equal(v, v2) and np.array_equal(i, i2)                  # deterministic
+
+
+# ------------------------------------------------------------------ guarded build covers every device-derived index
+def test_every_device_derived_index_of_the_queue_kernels_is_guarded():
+    """In the staged pipeline's kernels, an index that comes out of device memory (queue positions from region
+    counts, node and triangle references, pixels carried by rays, stack spill slots) must pass through RTG(),
+    which a -DRT_GUARD=1 build turns into a range check.  This scans the sources for the array accesses that
+    take such indices and fails on one that bypasses the macro."""
+    src = open(os.path.join(ROOT, "raytracer_amd", "csrc", "wavefront.hip")).read()
+    body = src[src.index("void k_trace(TraceArgs A)"):src.index("int wavefront_trace_grid")]
+    guarded_arrays = {
+        r"A\.hits\[": "pixel", r"A\.occ\[": "pixel", r"A\.q_o\[|A\.q_d\[": "queue", r"A\.nq_o\[|A\.nq_d\[": "queue",
+        r"A\.sq_o\[|A\.sq_d\[": "queue",
+    }
+    bad = []
+    for line_no, line in enumerate(body.splitlines(), 1):
+        code = line.split("//")[0]
+        for pat in guarded_arrays:
+            for mm in re.finditer(pat, code):
+                rest = code[mm.end():]
+                idx = rest[:rest.index("]")] if "]" in rest else rest
+                # the index is either an RTG(...) expression or a local that was assigned from one on an earlier line
+                if "RTG(" in idx or re.fullmatch(r"\s*(q|dst|r\.pixel)\s*", idx):
+                    continue
+                bad.append((line_no, line.strip()))
+    assert not bad, bad
+    # the locals accepted above are themselves produced by RTG
+    assert re.search(r"const size_t q = \(size_t\)RTG\(", body) and re.search(r"const size_t dst = \(size_t\)RTG\(", body)
+    assert "r.pixel = (int)RTG(r.pixel, A.n_pixels)" in body
+    # node, triangle and spill-slot references
+    assert "RTG(node, A.n_wnodes)" in body and "RTG(tri_i, sc.n_tris)" in body and body.count("RTG(sp - WF_LDS_STACK, WF_OVF)") == 2
+    assert os.path.exists(os.path.join(ROOT, "raytracer_amd", "variants", "guard.so")), "build() must also produce the guarded variant"
