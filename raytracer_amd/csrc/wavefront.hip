@@ -73,6 +73,13 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_MERGE
 #define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
 #endif
+#ifndef WF_IKEY
+#define WF_IKEY 1          // 1: hit flag and entry distance of a child in one signed integer key (see the node step)
+#endif
+#ifndef WF_AFFINE
+#define WF_AFFINE 0        // 1: a shard claims a contiguous range of regions (of every segment) instead of every n_shards-th unit,
+                           //    and the shards of one XCD (blocks b, b + 8, ... share one) hold neighbouring ranges
+#endif
 #ifndef WF_WAVES_EU
 #define WF_WAVES_EU 8      // register budget and resident blocks per CU of k_trace
 #endif
@@ -155,9 +162,17 @@ void k_trace(TraceArgs A)
     // Every shard needs an owner that drains it to the end: with fewer blocks than SHARDS only
     // gridDim.x shards are used.
     const int n_shards = (int)min((unsigned)SHARDS, gridDim.x);
-    const int max_probes = min(MAX_PROBES, n_shards);
+    const int max_probes = min(WF_AFFINE ? 24 : MAX_PROBES, n_shards);
     int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
     const unsigned int n_units = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0)) * (unsigned)A.n_regions * UPR;
+#if WF_AFFINE
+    // units of one segment per shard, and the place of a shard's range: shards s, s + 8, ... run on one XCD
+    const unsigned int per_seg_u = (unsigned)A.n_regions * UPR, n_segs_u = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0));
+    const unsigned int per_shard = (per_seg_u + (unsigned)n_shards - 1) / (unsigned)n_shards;
+    auto range_of = [&](int sh) -> unsigned int {
+        return n_shards == SHARDS ? (unsigned)((sh & 7) * (SHARDS / 8) + (sh >> 3)) : (unsigned)sh;
+    };
+#endif
     bool exhausted = n_units == 0;
     unsigned long long t_start = 0, t_exhaust = 0;
     if ((COUNT || WF_TIMES) && A.wave_times) t_start = t_exhaust = wall_clock64();
@@ -191,11 +206,37 @@ void k_trace(TraceArgs A)
                 // units are dealt to shards round-robin (unit = k*n_shards + shard); a wave drains its own
                 // shard to the end, then steals from the next few
                 unsigned int k = 0;
+#if WF_AFFINE
+                // a shard that is not this wave's own is looked at before it is claimed from: most are already drained
+                if (probes > 0) {
+                    unsigned int seen = 0;
+                    if (lane == 0) seen = __hip_atomic_load(&A.cursors[shard * CURSOR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+                    if (seen >= n_segs_u * per_shard) {
+                        shard = n_shards == SHARDS ? (probes < 7 ? (shard + 8) % SHARDS : (shard + 1) % SHARDS) : (shard + 1 == n_shards ? 0 : shard + 1);
+                        if (++probes >= max_probes) exhausted = true;
+                        continue;
+                    }
+                }
+#endif
                 if (lane == 0) k = atomicAdd(&A.cursors[shard * CURSOR_STRIDE], 1u);
                 k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+#if WF_AFFINE
+                // the shard's k-th claim: unit (k % per_shard) of its range in segment k / per_shard
+                const unsigned int seg_k = k / per_shard, in_seg = range_of(shard) * per_shard + k % per_shard;
+                const bool past = seg_k >= n_segs_u;
+                if (!past && in_seg >= per_seg_u) continue;             // the last range is shorter
+                const unsigned long long unit = past ? (unsigned long long)n_units : (unsigned long long)seg_k * per_seg_u + in_seg;
+#else
                 const unsigned long long unit = (unsigned long long)k * (unsigned)n_shards + (unsigned)shard;
+#endif
                 if (unit >= n_units) {
+#if WF_AFFINE
+                    // steal from the shards of the same XCD first (they hold the neighbouring ranges)
+                    shard = n_shards == SHARDS ? (probes < 7 ? (shard + 8) % SHARDS : (shard + 1) % SHARDS) : (shard + 1 == n_shards ? 0 : shard + 1);
+#else
                     shard = shard + 1 == n_shards ? 0 : shard + 1;
+#endif
                     if (++probes >= max_probes) {
                         exhausted = true;
                         if ((COUNT || WF_TIMES) && A.wave_times) t_exhaust = wall_clock64();
@@ -289,6 +330,59 @@ void k_trace(TraceArgs A)
                     const uint4 *np = (const uint4 *)((const char *)sc.wnodes + (unsigned)RTG(node, A.n_wnodes) * 64u);
                     qa = np[0]; qb = np[1]; qc = np[2]; qd = np[3];
                 }
+#if WF_IKEY
+                // Entry distance and hit flag of each child in ONE integer key: the bits of the (non-negative) entry
+                // distance, with the sign bit set when the box is hit, so that as signed integers hit children sort
+                // before missed ones and among themselves by distance.  The flag comes from the sign of far - near
+                // (a subtraction and one three-input bit operation, both full-rate instructions) instead of a
+                // compare and a select.  Unused slots hold an inverted box and always miss.
+                int dk[4];
+                int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
+                {
+                    const unsigned int wx[4] = { qa.x, qa.w, qb.z, qc.y }, wy[4] = { qa.y, qb.x, qb.w, qc.z },
+                                       wz[4] = { qa.z, qb.y, qc.x, qc.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const V2 x = plane_pair(wx[k], sel_n.x, sel_f.x, inv.x, oi.x), y = plane_pair(wy[k], sel_n.y, sel_f.y, inv.y, oi.y),
+                                 z = plane_pair(wz[k], sel_n.z, sel_f.z, inv.z, oi.z);
+                        const float nk = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), 0.0f);
+                        const float fk = fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), tmax);
+                        // nk | (~(fk - nk) & sign): one v_bitop3_b32 (truth table 0xF2 = a | (~b & c))
+                        dk[k] = __builtin_amdgcn_bitop3_b32(__float_as_int(nk), __float_as_int(fk - nk), (int)0x80000000, 0xF2);
+                    }
+                }
+                if (COUNT) tl.box += 4;
+#define WF_CSWAP(a, b)                                                          \
+                {                                                               \
+                    const bool sw = dk[b] < dk[a];                              \
+                    const int td = sw ? dk[b] : dk[a];                          \
+                    const int tr = sw ? rk[b] : rk[a];                          \
+                    dk[b] = sw ? dk[a] : dk[b];                                 \
+                    rk[b] = sw ? rk[a] : rk[b];                                 \
+                    dk[a] = td;                                                 \
+                    rk[a] = tr;                                                 \
+                }
+                // nearest child to slot 0; the other hits are pushed in slot order
+                WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2)
+#undef WF_CSWAP
+                if (dk[0] >= 0) {
+                    pop();
+                } else if (sp + 3 <= WF_LDS_STACK) {
+                    // branch-free push: every slot is stored, a miss lands on the position the next
+                    // hit (or a later push) overwrites
+                    const int c3 = (int)((unsigned)dk[3] >> 31), c2 = (int)((unsigned)dk[2] >> 31), c1 = (int)((unsigned)dk[1] >> 31);
+                    stack[sp * BLOCK] = rk[3];
+                    stack[(sp + c3) * BLOCK] = rk[2];
+                    stack[(sp + c3 + c2) * BLOCK] = rk[1];
+                    sp += c3 + c2 + c1;
+                    node = rk[0];
+                } else {
+                    if (dk[3] < 0) push(rk[3]);
+                    if (dk[2] < 0) push(rk[2]);
+                    if (dk[1] < 0) push(rk[1]);
+                    node = rk[0];
+                }
+#else
                 float dk[4];
                 int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
                 {
@@ -348,6 +442,7 @@ void k_trace(TraceArgs A)
                     if (dk[1] < FLT_MAX) push(rk[1]);
                     node = rk[0];
                 }
+#endif
 #endif
 #else
                 // ---- both children's lattice boxes from one 32-byte node
@@ -507,10 +602,40 @@ __device__ __forceinline__ unsigned int block_rank(bool flag, unsigned int *s_cn
     return before + (unsigned)__popcll(mask & lanemask_lt());
 }
 
+#ifndef WF_OCTSORT
+#define WF_OCTSORT 0       // 1: the next level's rays of a region are written grouped by the octant of their direction
+#endif
+// Rank of this thread among the block's threads with `flag` set when those are ordered by (key, thread): a stable
+// counting sort on a 3-bit key.  s_tab: 8 * (BLOCK / 64) LDS words.  Two barriers; every thread must call it.
+__device__ __forceinline__ unsigned int block_rank_keyed(bool flag, unsigned int key, unsigned int *s_tab, unsigned int &total)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long mine = 0ull;
+    for (unsigned int k = 0; k < 8; k++) {
+        const unsigned long long m = __ballot(flag && key == k);
+        if ((unsigned)lane == k) s_tab[k * (BLOCK / 64) + wave] = (unsigned)__popcll(m);
+        if (key == k) mine = m;
+    }
+    __syncthreads();
+    unsigned int before = 0, all = 0;
+    for (unsigned int k = 0; k < 8; k++)
+        for (int w = 0; w < BLOCK / 64; w++) {
+            const unsigned int c = s_tab[k * (BLOCK / 64) + w];
+            if (k < key || (k == key && w < wave)) before += c;
+            all += c;
+        }
+    __syncthreads();
+    total = all;
+    return before + (unsigned)__popcll(mine & lanemask_lt());
+}
+
 template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
 {
     __shared__ unsigned int s_cnt[BLOCK / 64];
+#if WF_OCTSORT
+    __shared__ unsigned int s_tab[8 * (BLOCK / 64)];
+#endif
     const DevScene &sc = A.sc;
     Tally tl = { 0u, 0u, 0u };
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
@@ -532,7 +657,12 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
                 if (spawn) R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));            // main.cpp:210
             }
             unsigned int total;
+#if WF_OCTSORT
+            const unsigned int oct = (R.x < 0.0f ? 1u : 0u) | (R.y < 0.0f ? 2u : 0u) | (R.z < 0.0f ? 4u : 0u);
+            const unsigned int rank = block_rank_keyed(spawn, oct, s_tab, total);
+#else
             const unsigned int rank = block_rank(spawn, s_cnt, total);
+#endif
             if (spawn) {
                 const size_t dst = (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
