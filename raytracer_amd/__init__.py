@@ -19,6 +19,7 @@ OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING, OPT_PIPELINE = 1, 2, 3, 4,
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT = 0, 1, 2, 3
 OPT_BUILDER = 6
 OPT_GRAPH = 7
+OPT_SPLIT = 8
 BUILDER_AUTO, BUILDER_LBVH, BUILDER_PLOC = 0, 1, 2
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48

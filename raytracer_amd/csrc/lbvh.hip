@@ -124,6 +124,164 @@ __global__ __launch_bounds__(256) void k_bounds(const float4 *__restrict__ tri_m
     }
 }
 
+// ------------------------------------------------------------------ triangle references (split large triangles)
+// A hierarchy over whole-triangle boxes handles one shape badly: a triangle that is long or large against its
+// neighbours, and not aligned with an axis, has a box that is mostly empty space, and every ray through that space
+// pays a triangle test.  The hierarchy is therefore built over REFERENCES: a triangle whose box is longer than
+// 1/SPLIT_RES of the scene is cut by a grid of cells along its two longest box axes (at most `max_cells` per axis),
+// and every cell the triangle reaches becomes one reference whose box is the box of the triangle clipped to the cell.
+// A reference still points to the whole triangle and the intersector runs on the whole triangle
+// (Raytracer/main.cpp:109-129), so hit ids and distances do not change: a triangle found through two references gives
+// the same (t, id) twice.  Ordinary triangles get exactly one reference with their own box.
+constexpr float SPLIT_RES = 64.0f;
+
+struct SplitGrid {
+    int n[3];              // cells per axis (1 = axis not cut)
+    float lo[3], hi[3];    // the triangle's box
+    float v[3][3];         // the three corners the intersector sees: v1, v1+e1, v1+e2
+};
+
+__device__ inline SplitGrid split_grid(const float4 *__restrict__ tri_mt, int i, const unsigned int *__restrict__ bounds, int max_cells)
+{
+    SplitGrid g;
+    const float4 a = tri_mt[3 * (size_t)i], e1 = tri_mt[3 * (size_t)i + 1], e2 = tri_mt[3 * (size_t)i + 2];
+    g.v[0][0] = a.x; g.v[0][1] = a.y; g.v[0][2] = a.z;
+    g.v[1][0] = a.x + e1.x; g.v[1][1] = a.y + e1.y; g.v[1][2] = a.z + e1.z;
+    g.v[2][0] = a.x + e2.x; g.v[2][1] = a.y + e2.y; g.v[2][2] = a.z + e2.z;
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) ext = fmaxf(ext, ordered_to_float(bounds[3 + k]) - ordered_to_float(bounds[k]));
+    const float h = ext / SPLIT_RES;
+    int smallest = 0;
+    for (int k = 0; k < 3; k++) {
+        g.lo[k] = fminf(g.v[0][k], fminf(g.v[1][k], g.v[2][k]));
+        g.hi[k] = fmaxf(g.v[0][k], fmaxf(g.v[1][k], g.v[2][k]));
+        const float e = g.hi[k] - g.lo[k];
+        g.n[k] = 1;
+        if (max_cells > 1 && h > 0.f && e > h && e < FLT_MAX) g.n[k] = min(max_cells, (int)ceilf(e / h));     // (a NaN or infinite extent is never cut)
+        if (g.n[k] < g.n[smallest]) smallest = k;
+    }
+    g.n[smallest] = 1;     // a triangle is flat: two axes of cells reach every part of it
+    return g;
+}
+
+// Boundary j of axis k's cells; the same expression from both sides, so neighbouring cells share it exactly.
+__device__ inline float split_bound(const SplitGrid &g, int k, int j)
+{
+    return j <= 0 ? g.lo[k] : j >= g.n[k] ? g.hi[k] : g.lo[k] + (g.hi[k] - g.lo[k]) * ((float)j / (float)g.n[k]);
+}
+
+// Sutherland-Hodgman against one axis plane, closed half-space (points on the plane are kept).
+__device__ inline int clip_plane(const float (*p)[3], int np, int ax, float bound, bool keep_ge, float (*q)[3])
+{
+    int nq = 0;
+    for (int i = 0; i < np; i++) {
+        const float *a = p[i], *b = p[i + 1 == np ? 0 : i + 1];
+        const bool ia = keep_ge ? a[ax] >= bound : a[ax] <= bound, ib = keep_ge ? b[ax] >= bound : b[ax] <= bound;
+        if (ia) { q[nq][0] = a[0]; q[nq][1] = a[1]; q[nq][2] = a[2]; nq++; }
+        if (ia != ib) {
+            const float t = (bound - a[ax]) / (b[ax] - a[ax]);
+            for (int k = 0; k < 3; k++) q[nq][k] = k == ax ? bound : a[k] + (b[k] - a[k]) * t;
+            nq++;
+        }
+    }
+    return nq;
+}
+
+// Box of the triangle inside cell (c[0], c[1], c[2]); false when the triangle does not reach the cell.
+__device__ inline bool split_cell_box(const SplitGrid &g, const int c[3], float lo[3], float hi[3])
+{
+    float p[10][3], q[10][3];
+    int np = 3;
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) p[i][k] = g.v[i][k];
+    for (int k = 0; k < 3; k++) {
+        if (g.n[k] == 1) continue;
+        np = clip_plane(p, np, k, split_bound(g, k, c[k]), true, q);
+        if (np == 0) return false;
+        np = clip_plane(q, np, k, split_bound(g, k, c[k] + 1), false, p);
+        if (np == 0) return false;
+    }
+    for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+    for (int i = 0; i < np; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], p[i][k]); hi[k] = fmaxf(hi[k], p[i][k]); }
+    for (int k = 0; k < 3; k++) {        // never outside the triangle's own box or the cell
+        lo[k] = fmaxf(lo[k], g.n[k] > 1 ? split_bound(g, k, c[k]) : g.lo[k]);
+        hi[k] = fminf(hi[k], g.n[k] > 1 ? split_bound(g, k, c[k] + 1) : g.hi[k]);
+    }
+    return true;
+}
+
+// counts[i] = cells of triangle i's grid (1 for a triangle that is not cut)
+__global__ void k_split_count(const float4 *__restrict__ tri_mt, int n, const unsigned int *__restrict__ bounds, int max_cells,
+                              unsigned int *counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SplitGrid g = split_grid(tri_mt, i, bounds, max_cells);
+    counts[i] = (unsigned)(g.n[0] * g.n[1] * g.n[2]);
+}
+
+// One thread per cell of every triangle's grid (cell_off = exclusive scan of the counts, n_cells their sum): the box of
+// the triangle inside the cell and whether the triangle reaches it at all.  A triangle's corner always lies in one of
+// its (closed) cells, so every triangle keeps at least one reference.
+__global__ void k_split_cells(const float4 *__restrict__ tri_mt, int n, const unsigned int *__restrict__ bounds, int max_cells,
+                              const unsigned int *__restrict__ cell_off, unsigned int n_cells, unsigned int *cell_tri, float4 *cell_lo,
+                              float4 *cell_hi, unsigned int *flags)
+{
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cells) return;
+    // the triangle whose range of cells holds idx: the last i with cell_off[i] <= idx
+    int lo_i = 0, hi_i = n - 1;
+    while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i + 1) >> 1;
+        if (cell_off[mid] <= idx) lo_i = mid; else hi_i = mid - 1;
+    }
+    const int i = lo_i;
+    const SplitGrid g = split_grid(tri_mt, i, bounds, max_cells);
+    const int j = (int)(idx - cell_off[i]);
+    float lo[3] = { g.lo[0], g.lo[1], g.lo[2] }, hi[3] = { g.hi[0], g.hi[1], g.hi[2] };
+    bool keep = true;
+    if (g.n[0] * g.n[1] * g.n[2] > 1) {
+        const int c[3] = { j % g.n[0], (j / g.n[0]) % g.n[1], j / (g.n[0] * g.n[1]) };
+        keep = split_cell_box(g, c, lo, hi);
+    }
+    cell_tri[idx] = (unsigned)i;
+    cell_lo[idx] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    cell_hi[idx] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    flags[idx] = keep ? 1u : 0u;
+}
+
+// The cells a triangle reaches, in order, become the references (dst = exclusive scan of the flags).
+__global__ void k_split_compact(const unsigned int *__restrict__ cell_tri, const float4 *__restrict__ cell_lo, const float4 *__restrict__ cell_hi,
+                                const unsigned int *__restrict__ dst, unsigned int n_cells, unsigned int m, unsigned int *ref_tri, float4 *ref_lo,
+                                float4 *ref_hi)
+{
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cells) return;
+    const unsigned int at = dst[idx], next = idx + 1 < n_cells ? dst[idx + 1] : m;
+    if (next == at || at >= m) return;          // flag was 0
+    ref_tri[at] = cell_tri[idx];
+    ref_lo[at] = cell_lo[idx];
+    ref_hi[at] = cell_hi[idx];
+}
+
+__global__ void k_ref_identity(int n, unsigned int *ref_tri)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) ref_tri[r] = (unsigned)r;
+}
+
+// The references of a refit: the triangles moved, so every reference falls back to its whole triangle's box.
+__global__ void k_ref_boxes_whole(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ ref_tri, int m, float4 *ref_lo, float4 *ref_hi)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    float lo[3], hi[3];
+    tri_box(tri_mt, (int)ref_tri[r], lo, hi);
+    ref_lo[r] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    ref_hi[r] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
 __device__ inline unsigned long long expand21(unsigned long long v)
 {
     v &= 0x1fffffull;
@@ -135,13 +293,13 @@ __device__ inline unsigned long long expand21(unsigned long long v)
     return v;
 }
 
-__global__ void k_morton(const float4 *__restrict__ tri_mt, int n, const unsigned int *__restrict__ bounds,
+__global__ void k_morton(const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi, int n, const unsigned int *__restrict__ bounds,
                          unsigned long long *keys, unsigned int *vals)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float lo[3], hi[3];
-    tri_box(tri_mt, i, lo, hi);
+    const float4 l4 = ref_lo[i], h4 = ref_hi[i];
+    const float lo[3] = { l4.x, l4.y, l4.z }, hi[3] = { h4.x, h4.y, h4.z };
     unsigned long long code = 0;
     // one cell size for all three axes (the longest scene extent): cubic cells split better than
     // cells stretched to each axis' own extent
@@ -465,13 +623,13 @@ __global__ __launch_bounds__(256) void k_node_depth(const int *__restrict__ pare
 // Leaf boxes: the intersector's triangle, padded so that rounding in the
 // Möller–Trumbore test (which can accept a ray passing slightly outside the exact
 // triangle) never lets the slab test cull a triangle the reference would hit.
-__global__ void k_leaf_boxes(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals, int n,
+__global__ void k_leaf_boxes(const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi, const unsigned int *__restrict__ sorted_vals, int n,
                              const unsigned int *__restrict__ bounds, float4 *box_lo, float4 *box_hi)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    float lo[3], hi[3];
-    tri_box(tri_mt, (int)sorted_vals[k], lo, hi);
+    const float4 l4 = ref_lo[sorted_vals[k]], h4 = ref_hi[sorted_vals[k]];
+    float lo[3] = { l4.x, l4.y, l4.z }, hi[3] = { h4.x, h4.y, h4.z };
     float scene_abs = 0.f;
     for (int a = 0; a < 3; a++)
         scene_abs = fmaxf(scene_abs, fmaxf(fabsf(ordered_to_float(bounds[a])), fabsf(ordered_to_float(bounds[3 + a]))));
@@ -778,12 +936,12 @@ __global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restric
 }
 
 
-__global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ sorted_vals,
+__global__ void k_gather_tris(const float4 *__restrict__ tri_mt, const unsigned int *__restrict__ ref_tri, const unsigned int *__restrict__ sorted_vals,
                               const int *__restrict__ order, int n, float4 *bvh_tri)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    unsigned int src = sorted_vals[order ? order[k] : k];
+    unsigned int src = ref_tri[sorted_vals[order ? order[k] : k]];
     float4 a = tri_mt[3 * (size_t)src], e1 = tri_mt[3 * (size_t)src + 1], e2 = tri_mt[3 * (size_t)src + 2];
     a.w = __int_as_float((int)src);
     bvh_tri[3 * (size_t)k] = a;
@@ -826,9 +984,12 @@ void scan_exclusive(T *data, int m, T *total, T *scratch, hipStream_t stream)
 // What a refit needs from the build: the binary tree over the sorted triangles and the numbering of
 // the emitted nodes.  None of it depends on where the vertices are, only on which triangle sits where.
 struct LbvhTopology {
-    int n = 0, max_depth = 0;
+    int n = 0, max_depth = 0;          // n = references (leaves of the binary tree)
+    int n_tris = 0;
     bool ploc = false;
     unsigned int *bounds = nullptr, *vals = nullptr;
+    unsigned int *ref_tri = nullptr;   // [n] triangle of every reference
+    float4 *ref_lo = nullptr, *ref_hi = nullptr;   // [n] reference boxes (unpadded)
     int2 *children = nullptr, *range = nullptr;
     int *parent = nullptr, *depth = nullptr, *scalars = nullptr, *leafpos = nullptr, *order = nullptr;
     int *live = nullptr, *pre = nullptr, *pre4 = nullptr, *slot = nullptr, *root = nullptr;
@@ -837,7 +998,8 @@ struct LbvhTopology {
     QuantGrid *grid = nullptr;
     ~LbvhTopology()
     {
-        void *ptrs[] = { bounds, vals, children, range, parent, depth, scalars, leafpos, order, live, pre, pre4, slot, root, wkids, box_lo, box_hi, grid };
+        void *ptrs[] = { bounds, vals, children, range, parent, depth, scalars, leafpos, order, live, pre, pre4, slot, root, wkids, box_lo, box_hi, grid,
+                         ref_tri, ref_lo, ref_hi };
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
     }
@@ -888,24 +1050,27 @@ struct EventPair {
     }
 };
 
-int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err);
+int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
+                    std::string *err);
 
 }  // namespace
 
 // Every failure leaves `out` empty: a half-built hierarchy (arrays allocated, depth and leaf size unset) is never kept.
-int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err)
+int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
+               std::string *err)
 {
     lbvh_free(out);
-    const int rc = lbvh_build_impl(tri_mt, n, leaf_max, builder, stream, out, err);
+    const int rc = lbvh_build_impl(tri_mt, n, leaf_max, builder, split_cells, stream, out, err);
     if (rc != RT_OK) lbvh_free(out);
     return rc;
 }
 
 namespace {
 
-int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipStream_t stream, LbvhResult *out, std::string *err)
+int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
+                    std::string *err)
 {
-    if (n < 2) {
+    if (n_tris < 2) {
         if (err) *err = "lbvh_build needs at least 2 triangles";
         return RT_E_INVALID;
     }
@@ -913,23 +1078,95 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
         if (err) *err = "leaf_max must be 1..8";
         return RT_E_INVALID;
     }
-    if ((long long)n * 8 >= (1ll << 31)) {
-        if (err) *err = "triangle count beyond the leaf encoding (2^28)";
+    if (split_cells < 1 || split_cells > 32) {
+        if (err) *err = "split cells per axis must be 1..32";
+        return RT_E_INVALID;
+    }
+    EventPair ev;
+    RT_HIP_CHECK(ev.create(), err);
+    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
+    RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
+
+    // ---- scene bounds, then the references: one per triangle, more for the triangles that are cut
+    DevBuf<unsigned int> bounds, counts, total, ref_tri;
+    DevBuf<float4> ref_lo, ref_hi;
+    if (bounds.alloc(6) != hipSuccess || counts.alloc(n_tris) != hipSuccess || total.alloc(1) != hipSuccess) {
+        if (err) *err = "lbvh_build allocation: reference counts";
+        return RT_E_NOMEM;
+    }
+    const int GT = blocks_for(n_tris, 256);
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds.p);
+    hipLaunchKernelGGL(k_bounds, dim3(GT < 256 ? GT : 256), dim3(256), 0, stream, tri_mt, n_tris, bounds.p);
+    unsigned int m_refs = (unsigned)n_tris;
+    if (split_cells > 1) {
+        DevBuf<unsigned int> scan_tmp, cell_tri, flags;
+        DevBuf<float4> cell_lo, cell_hi;
+        if (scan_tmp.alloc((size_t)blocks_for(n_tris, 4096) + 1) != hipSuccess) {
+            if (err) *err = "lbvh_build allocation: reference scan";
+            return RT_E_NOMEM;
+        }
+        hipLaunchKernelGGL(k_split_count, dim3(GT), dim3(256), 0, stream, tri_mt, n_tris, bounds.p, split_cells, counts.p);
+        scan_exclusive<unsigned int>(counts.p, n_tris, total.p, scan_tmp.p, stream);
+        unsigned int n_cells = 0;
+        RT_HIP_CHECK(hipMemcpyAsync(&n_cells, total.p, sizeof n_cells, hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+        if (n_cells < (unsigned)n_tris || n_cells >= (1u << 30)) {
+            if (err) *err = "triangle split grid out of range";
+            return n_cells < (unsigned)n_tris ? RT_E_DEVICE : RT_E_LIMIT;
+        }
+        if (n_cells > (unsigned)n_tris) {            // some triangle is cut
+            DevBuf<unsigned int> scan_tmp2;
+            if (cell_tri.alloc(n_cells) != hipSuccess || flags.alloc(n_cells) != hipSuccess || cell_lo.alloc(n_cells) != hipSuccess ||
+                cell_hi.alloc(n_cells) != hipSuccess || scan_tmp2.alloc((size_t)blocks_for((int)n_cells, 4096) + 1) != hipSuccess) {
+                if (err) *err = "lbvh_build allocation: split cells";
+                return RT_E_NOMEM;
+            }
+            const int GC = blocks_for((int)n_cells, 256);
+            hipLaunchKernelGGL(k_split_cells, dim3(GC), dim3(256), 0, stream, tri_mt, n_tris, bounds.p, split_cells, counts.p, n_cells, cell_tri.p,
+                               cell_lo.p, cell_hi.p, flags.p);
+            scan_exclusive<unsigned int>(flags.p, (int)n_cells, total.p, scan_tmp2.p, stream);
+            RT_HIP_CHECK(hipMemcpyAsync(&m_refs, total.p, sizeof m_refs, hipMemcpyDeviceToHost, stream), err);
+            RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+            if (m_refs < (unsigned)n_tris || m_refs > n_cells) {
+                if (err) *err = "reference count out of range";
+                return RT_E_DEVICE;
+            }
+            if (ref_tri.alloc(m_refs) != hipSuccess || ref_lo.alloc(m_refs) != hipSuccess || ref_hi.alloc(m_refs) != hipSuccess) {
+                if (err) *err = "lbvh_build allocation: references";
+                return RT_E_NOMEM;
+            }
+            hipLaunchKernelGGL(k_split_compact, dim3(GC), dim3(256), 0, stream, cell_tri.p, cell_lo.p, cell_hi.p, flags.p, n_cells, m_refs,
+                               ref_tri.p, ref_lo.p, ref_hi.p);
+            RT_HIP_CHECK(hipStreamSynchronize(stream), err);      // the cell arrays go out of scope here
+        }
+    }
+    if ((long long)m_refs * 8 >= (1ll << 31)) {
+        if (err) *err = "reference count beyond the leaf encoding (2^28)";
         return RT_E_LIMIT;
     }
-    if (((long long)n + WIDE_TOP_NODES) * (long long)sizeof(BvhNode4) >= (1ll << 32)) {
-        if (err) *err = "triangle count beyond the 32-bit byte offsets of the wide node array (2^26)";
+    if (((long long)m_refs + WIDE_TOP_NODES) * (long long)sizeof(BvhNode4) >= (1ll << 32)) {
+        if (err) *err = "reference count beyond the 32-bit byte offsets of the wide node array (2^26)";
         return RT_E_LIMIT;
     }
+    const int n = (int)m_refs;          // leaves of the hierarchy from here on
+    if (!ref_tri.p) {                   // nothing was cut: reference i is triangle i with its own box
+        if (ref_tri.alloc(n) != hipSuccess || ref_lo.alloc(n) != hipSuccess || ref_hi.alloc(n) != hipSuccess) {
+            if (err) *err = "lbvh_build allocation: references";
+            return RT_E_NOMEM;
+        }
+        hipLaunchKernelGGL(k_ref_identity, dim3(GT), dim3(256), 0, stream, n, ref_tri.p);
+        hipLaunchKernelGGL(k_ref_boxes_whole, dim3(GT), dim3(256), 0, stream, tri_mt, (const unsigned int *)ref_tri.p, n, ref_lo.p, ref_hi.p);
+    }
+
     const int n_tiles = blocks_for(n, SORT_TILE);
-    DevBuf<unsigned int> bounds, vals[2], hist;
+    DevBuf<unsigned int> vals[2], hist;
     DevBuf<unsigned long long> keys[2];
     DevBuf<int2> children, range;
     DevBuf<int> parent, depth, scalars;
     DevBuf<float4> box_lo, box_hi;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    A(bounds.alloc(6)); A(vals[0].alloc(n)); A(vals[1].alloc(n)); A(keys[0].alloc(n)); A(keys[1].alloc(n));
+    A(vals[0].alloc(n)); A(vals[1].alloc(n)); A(keys[0].alloc(n)); A(keys[1].alloc(n));
     A(hist.alloc((size_t)256 * n_tiles)); A(children.alloc(n)); A(range.alloc(n)); A(parent.alloc(2 * (size_t)n));
     A(depth.alloc(n)); A(scalars.alloc(4)); A(box_lo.alloc(2 * (size_t)n)); A(box_hi.alloc(2 * (size_t)n));
     DevBuf<QuantGrid> grid;
@@ -947,15 +1184,8 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
         lbvh_free(out);
         return RT_E_NOMEM;
     }
-    EventPair ev;
-    RT_HIP_CHECK(ev.create(), err);
-    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
-    RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
-
     const int B = 256, G = blocks_for(n, B);
-    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds.p);
-    hipLaunchKernelGGL(k_bounds, dim3(G < 256 ? G : 256), dim3(256), 0, stream, tri_mt, n, bounds.p);
-    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, tri_mt, n, bounds.p, keys[0].p, vals[0].p);
+    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, n, bounds.p, keys[0].p, vals[0].p);
     int cur = 0;
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
@@ -973,7 +1203,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
     DevBuf<unsigned long long> flags, totals;
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
     if (!ploc) {
         hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
                            parent.p);
@@ -1067,7 +1297,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
                            wl, slot.p);
     hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, range.p, live.p, root.p, wkids.p, n, leaf_max,
                        box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, slot.p, out->wnodes, scalars.p + 2);
-    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
+    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, ref_tri.p, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
     RT_HIP_CHECK(hipEventRecord(ev1, stream), err);
@@ -1079,13 +1309,16 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     out->n_nodes = n - 1;
+    out->n_refs = n;
+    out->split = split_cells;
     out->depth = live_depth;
     out->wide_depth = wide_depth;
     out->leaf_max = leaf_max;
     out->ms_build = ms;
     LbvhTopology *t = new (std::nothrow) LbvhTopology;
     if (t) {
-        t->n = n; t->max_depth = max_depth; t->ploc = ploc;
+        t->n = n; t->n_tris = n_tris; t->max_depth = max_depth; t->ploc = ploc;
+        t->ref_tri = ref_tri.release(); t->ref_lo = ref_lo.release(); t->ref_hi = ref_hi.release();
         t->bounds = bounds.release(); t->vals = vals[cur].release();
         t->children = children.release(); t->range = range.release(); t->parent = parent.release();
         t->depth = depth.release(); t->scalars = scalars.release();
@@ -1102,10 +1335,10 @@ int lbvh_build_impl(const float4 *tri_mt, int n, int leaf_max, int builder, hipS
 // New vertex positions under the same tree: leaf boxes, bottom-up unions, then the node arrays and the
 // triangle copy are written again.  The lattice follows the new root box.  Which triangles share a leaf
 // does not change, so a large deformation costs traversal steps, never correctness.
-int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out, std::string *err)
+int lbvh_refit(const float4 *tri_mt, int n_tris, hipStream_t stream, LbvhResult *out, std::string *err)
 {
     LbvhTopology *t = out->topo;
-    if (!t || !out->wnodes || t->n != n) {
+    if (!t || !out->wnodes || t->n_tris != n_tris) {
         if (err) *err = "lbvh_refit: no hierarchy over this many triangles";
         return RT_E_STATE;
     }
@@ -1113,18 +1346,21 @@ int lbvh_refit(const float4 *tri_mt, int n, hipStream_t stream, LbvhResult *out,
     RT_HIP_CHECK(ev.create(), err);
     const hipEvent_t ev0 = ev.a, ev1 = ev.b;
     RT_HIP_CHECK(hipEventRecord(ev0, stream), err);
-    const int B = 256, G = blocks_for(n, B), GI = blocks_for(n - 1, B);
+    const int n = t->n;
+    const int B = 256, G = blocks_for(n, B), GI = blocks_for(n - 1, B), GT = blocks_for(n_tris, B);
     const int *leafpos = t->ploc ? t->leafpos : (const int *)nullptr;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, t->bounds);
-    hipLaunchKernelGGL(k_bounds, dim3(G < 256 ? G : 256), dim3(256), 0, stream, tri_mt, n, t->bounds);
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, n, t->bounds, t->box_lo, t->box_hi);
+    hipLaunchKernelGGL(k_bounds, dim3(GT < 256 ? GT : 256), dim3(256), 0, stream, tri_mt, n_tris, t->bounds);
+    // the cells a triangle was cut by belong to where it was: after a move every reference takes its whole triangle's box
+    hipLaunchKernelGGL(k_ref_boxes_whole, dim3(G), dim3(B), 0, stream, tri_mt, t->ref_tri, n, t->ref_lo, t->ref_hi);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, t->ref_lo, t->ref_hi, t->vals, n, t->bounds, t->box_lo, t->box_hi);
     for (int level = t->max_depth; level >= 0; level--)
         hipLaunchKernelGGL(k_refit_level, dim3(GI), dim3(B), 0, stream, t->children, t->depth, n - 1, level, t->box_lo, t->box_hi);
     hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->parent, t->depth, n, out->leaf_max,
                        t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, out->qnodes, t->grid, t->scalars + 1);
     hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->range, t->live, t->root, t->wkids, n, out->leaf_max, t->box_lo,
                        t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
-    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->vals, t->ploc ? t->order : (const int *)nullptr, n,
+    hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->ref_tri, t->vals, t->ploc ? t->order : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
     RT_HIP_CHECK(hipEventRecord(ev1, stream), err);

@@ -82,6 +82,7 @@ struct DevScene {
     QuantGrid grid;
     const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
     int32_t n_analytic, n_lights, n_tris, accel;
+    int32_t n_refs;                // entries of bvh_tri: triangle references (>= n_tris when large triangles were cut)
 };
 
 struct DevCamera {
@@ -114,11 +115,12 @@ struct LbvhResult {
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
     int n_nodes = 0, depth = 0, wide_depth = 0, leaf_max = 0, builder = 0;
+    int n_refs = 0, split = 0;     // triangle references under the hierarchy; cells per axis a triangle was allowed to be cut into
     float ms_build = 0.f;
 };
 
 // lbvh.hip: builds the LBVH over tri_mt (device) on `stream`.  Returns RT_* code.
-int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, int builder, hipStream_t stream, LbvhResult *out,
+int lbvh_build(const float4 *tri_mt, int n_tris, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
                std::string *err);
 void lbvh_free(LbvhResult *r);
 // lbvh.hip: the same tree over moved vertices (same triangle count and order as the build).

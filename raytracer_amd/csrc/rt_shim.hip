@@ -68,7 +68,7 @@ struct rt_ctx {
     int n_mats = 0;
     LbvhResult bvh;
     // options
-    int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0;
+    int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0, opt_split = 0;
     DevCamera cam;
     FrameWorkspace ws;
     // replay of the last frame's launches (RT_OPT_GRAPH, only with timing and test counting off)
@@ -309,14 +309,17 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
     return RT_OK;
 }
 
+// Cells per axis a large triangle may be cut into when the hierarchy is built (RT_OPT_SPLIT; 0 = the default).
+int split_cells(const rt_ctx *c) { return c->opt_split == 0 ? 32 : c->opt_split; }
+
 // Decide linear scan vs LBVH for this frame and make sure the LBVH exists when wanted.
 int ensure_accel(rt_ctx *c, int *accel)
 {
     bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
     if (c->n_tris < 2) want = false;
-    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder)) {
+    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder || c->bvh.split != split_cells(c))) {
         std::string err;
-        int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->opt_builder, c->stream, &c->bvh, &err);
+        int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->opt_builder, split_cells(c), c->stream, &c->bvh, &err);
         if (rc != RT_OK) return fail(rc, err);
         c->bvh.builder = c->opt_builder;
         if (c->bvh.depth > 64) {
@@ -363,6 +366,7 @@ DevScene device_scene(const rt_ctx *c, int accel)
     sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
     sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
+    sc.n_refs = c->bvh.n_refs;
     return sc;
 }
 
@@ -554,6 +558,10 @@ int rt_set_option(rt_ctx *c, int option, int value)
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_BUILDER takes 0, 1 or 2");
         c->opt_builder = value;
         return RT_OK;
+    case RT_OPT_SPLIT:
+        if (value < 0 || value > 32) return fail(RT_E_INVALID, "RT_OPT_SPLIT takes 0..32");
+        c->opt_split = value;
+        return RT_OK;
     case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graph(c); return RT_OK;
     case RT_OPT_PIPELINE:
         if (value < 0 || value > 3) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0..3");
@@ -702,7 +710,7 @@ int after_vertex_update(rt_ctx *c)
 {
     c->state_version++;
     c->frame_valid = false;
-    if (c->bvh.wnodes && c->bvh.leaf_max == c->opt_leaf_max && c->bvh.builder == c->opt_builder) {
+    if (c->bvh.wnodes && c->bvh.leaf_max == c->opt_leaf_max && c->bvh.builder == c->opt_builder && c->bvh.split == split_cells(c)) {
         std::string err;
         int rc = lbvh_refit(c->d_tri_mt, c->n_tris, c->stream, &c->bvh, &err);
         if (rc != RT_OK) return fail(rc, err);
@@ -923,7 +931,7 @@ int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows
     // the hierarchy is built when the mesh is set; building it here would allocate
     bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
     if (c->n_tris < 2) want = false;
-    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder))
+    if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder || c->bvh.split != split_cells(c)))
         return fail(RT_E_STATE, "the hierarchy for the current options is not built: set the mesh after the options, or render once "
                                 "through rt_render_rows_device");
     const int accel = want ? 1 : 0;

@@ -477,7 +477,7 @@ void k_trace(TraceArgs A)
                 }
                 for (;;) {
                 // 32-bit byte offset (48 bytes per triangle; the builder's triangle limit keeps it below 4 GiB)
-                const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)RTG(tri_i, sc.n_tris) * 48u);
+                const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)RTG(tri_i, sc.n_refs) * 48u);
                 const float4 v1 = tp[0];
                 const F3 e1 = f3(tp[1]), e2 = f3(tp[2]);
                 float t;
@@ -749,7 +749,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     t.overflow = ws.overflow; t.total_lanes = (unsigned)trace_grid * BLOCK;
     t.counters = ws.counters;
     t.n_pix = (unsigned)n_pixels;
-    t.n_wnodes = (unsigned)(WIDE_TOP_NODES + (scene.n_tris > 1 ? scene.n_tris - 1 : 1));
+    t.n_wnodes = (unsigned)(WIDE_TOP_NODES + (scene.n_refs > 1 ? scene.n_refs - 1 : 1));
     t.q_cap = t.q2_cap = (unsigned long long)ws.pixels_cap;
 
     ShadeArgs s;

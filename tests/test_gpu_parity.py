@@ -910,3 +910,75 @@ def test_partitioned_renderer_is_ordered_by_streams_alone():
             want = ctx.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"]
             assert np.array_equal(g, want)
     assert any(not np.array_equal(got[0], g) for g in got[1:])      # the camera did move
+
+
+def _wires_and_walls_spec():
+    """What whole-triangle boxes handle worst: long thin triangles that cross the scene diagonally, a huge
+    two-triangle wall and floor, and small triangles scattered in the space their boxes cover."""
+    small = soup_spec(n_tris=300, seed=33)
+    v = [small.verts * np.array([1.0, 1.0, 1.0], np.float32) * 0.35 + np.array([0.0, -1.0, 1.0], np.float32)]
+    idx = [small.indices]
+    n0 = len(small.verts)
+    extra = []
+    for j in range(12):                                       # diagonal wires, 2 cm wide
+        a = np.array([-6.0 + j, -3.5, -1.0 + 0.3 * j]); b = np.array([5.0 - 0.5 * j, 3.0, 9.0 - 0.2 * j])
+        w = np.array([0.0, 0.02, 0.0])
+        extra += [a, b, b + w, a, b + w, a + w]
+    extra += [np.array(p, float) for p in ((-8, -4, -2), (-8, -4, 12), (8, -4, 12), (-8, -4, -2), (8, -4, 12), (8, -4, -2))]      # floor
+    extra += [np.array(p, float) for p in ((-8, -4, 12), (-8, 6, 12), (8, 6, 12), (-8, -4, 12), (8, 6, 12), (8, -4, 12))]        # back wall
+    ev = np.array(extra, np.float32)
+    v.append(ev)
+    idx.append(np.arange(len(ev), dtype=np.int32) + n0)
+    verts, indices = np.concatenate(v), np.concatenate(idx)
+    from common import SceneSpec
+    mats = [(0.0, 1.0, 1.0, (1.0, 1.0, 1.0)), (0.6, 0.7, 0.5, (0.9, 0.3, 0.2)), (1.0, 0.0, 1.0, (1.0, 1.0, 1.0)), (0.3, 1.0, 0.0, (0.2, 0.8, 0.4))]
+    tm = (np.arange(len(indices) // 3) % 4).astype(np.int32)
+    a = [sphere_((2.0, 5.0, 1.0), 0.1, True, (0.7, 0.7, 0.9)), sphere_((-2.0, 5.0, -3.0), 0.1, True, (0.9, 0.9, 0.4))]
+    return SceneSpec(a, verts, indices, mats=mats, tri_material=tm)
+
+
+def sphere_(p, r, light, col):
+    return dict(kind="sphere", p=p, s=r, mat=(0.0, 1.0, 1.0, col), is_light=light)
+
+
+@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC])
+def test_cut_triangle_references_change_the_tree_and_nothing_else(builder):
+    """RT_OPT_SPLIT: large triangles enter the hierarchy as several references with clipped boxes.  The frame (ids,
+    colours, ray counts) must equal the uncut hierarchy's and the oracle's brute-force scan; only the tree grows and
+    the triangle tests fall.  After a vertex update (references fall back to whole-triangle boxes) the same holds."""
+    spec = _wires_and_walls_spec()
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 160, 120, 3
+    r = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam))
+    out = {}
+    for split in (1, 0, 4):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+            ctx.set_option(rt.OPT_BUILDER, builder)
+            ctx.set_option(rt.OPT_SPLIT, split)
+            ctx.set_option(rt.OPT_COUNT_TESTS, 1)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            g = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            assert_parity(compare(g, r))
+            assert rays(st) == orays(r)
+            out[split] = (g, st)
+            if split == 0:
+                v = _moved(spec.verts, 1)
+                ctx.update_mesh_vertices(v)
+                g2 = ctx.render_frame(W, H, max_depth=D)
+                st2 = ctx.stats()
+                assert st2["bvh_nodes"] == st["bvh_nodes"]
+                r2 = to_oracle(SceneSpecCopy(spec, v)).render(W, H, max_depth=D, cam=ocam(cam))
+                assert_parity(compare(g2, r2))
+                assert rays(st2) == orays(r2)
+    n_tris = spec.n_tris
+    assert out[1][1]["bvh_nodes"] == n_tris - 1                       # never cut: one reference per triangle
+    assert out[0][1]["bvh_nodes"] > out[4][1]["bvh_nodes"] > n_tris - 1
+    for k in ("rgb8", "hit_id", "rgb32"):
+        assert np.array_equal(out[0][0][k].view(np.uint8), out[1][0][k].view(np.uint8)), k
+    assert out[0][1]["tri_tests"] < 0.6 * out[1][1]["tri_tests"]      # what the cut is for
+    with rt.Context(0) as ctx:
+        with pytest.raises(rt.RtError):
+            ctx.set_option(rt.OPT_SPLIT, 33)

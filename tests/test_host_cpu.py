@@ -295,5 +295,5 @@ def test_every_device_derived_index_of_the_queue_kernels_is_guarded():
     assert re.search(r"const size_t q = \(size_t\)RTG\(", body) and re.search(r"const size_t dst = \(size_t\)RTG\(", body)
     assert "r.pixel = (int)RTG(r.pixel, A.n_pixels)" in body
     # node, triangle and spill-slot references
-    assert "RTG(node, A.n_wnodes)" in body and "RTG(tri_i, sc.n_tris)" in body and body.count("RTG(sp - WF_LDS_STACK, WF_OVF)") == 2
+    assert "RTG(node, A.n_wnodes)" in body and "RTG(tri_i, sc.n_refs)" in body and body.count("RTG(sp - WF_LDS_STACK, WF_OVF)") == 2
     assert os.path.exists(os.path.join(ROOT, "raytracer_amd", "variants", "guard.so")), "build() must also produce the guarded variant"
