@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 
 RT_SPHERE, RT_PLANE = 0, 1
 OPT_ACCEL, OPT_COUNT_TESTS, OPT_LEAF_MAX, OPT_TIMING, OPT_PIPELINE = 1, 2, 3, 4, 5
-PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT = 0, 1, 2, 3
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 OPT_BUILDER = 6
 OPT_GRAPH = 7
 OPT_SPLIT = 8

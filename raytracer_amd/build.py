@@ -17,7 +17,7 @@ HOST_BIN = os.path.join(HERE, "bin", "raytracer")
 OBJHOST_LIB = os.path.join(HERE, "libobjhost.so")
 GUARD_LIB = os.path.join(HERE, "variants", "guard.so")
 
-HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "persistent.hip", "lbvh.hip"]
+HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "shade.hip", "lbvh.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the trace arithmetic must round like the reference's scalar x86 code:

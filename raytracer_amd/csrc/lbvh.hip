@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float4 *__restrict__ tri_m
 // A reference still points to the whole triangle and the intersector runs on the whole triangle
 // (Raytracer/main.cpp:109-129), so hit ids and distances do not change: a triangle found through two references gives
 // the same (t, id) twice.  Ordinary triangles get exactly one reference with their own box.
-constexpr float SPLIT_RES = 64.0f;
+#ifndef LBVH_SPLIT_RES
+#define LBVH_SPLIT_RES 64.0f
+#endif
+constexpr float SPLIT_RES = LBVH_SPLIT_RES;
 
 struct SplitGrid {
     int n[3];              // cells per axis (1 = axis not cut)

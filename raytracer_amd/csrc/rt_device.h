@@ -232,4 +232,32 @@ __device__ __forceinline__ Surface surface_at(const DevScene &sc, int id, F3 pos
     return s;
 }
 
+// main.cpp:210 — the mirror direction, evaluated as (N*2.0f)*(d.N)
+__device__ __forceinline__ F3 mirror_dir(F3 d, F3 N) { return sub(d, muls(muls(N, 2.0f), dot(d, N))); }
+
+// One light's contribution to a hit's local colour (main.cpp:191-204): un-clamped N.L diffuse, then the pow-20
+// specular of the incoming ray direction d against L mirrored about N; both are evaluated and then multiplied by
+// shade (1, or 0 when the shadow ray was blocked, main.cpp:175, 185), in the reference's operand order.
+__device__ __forceinline__ F3 add_light(F3 col, const Surface &s, F3 L, F3 Lc, F3 d, float shade)
+{
+    if (s.kd > 0.0f) {                                                           // main.cpp:191-195
+        const float diffuse = dot(s.N, L) * s.kd;
+        col = add(col, muls(muls(mulv(Lc, s.Mc), diffuse), shade));
+    }
+    if (s.ks > 0.0f) {                                                           // main.cpp:198-204
+        const F3 R = sub(L, muls(muls(s.N, dot(L, s.N)), 2.0f));
+        const float dt = dot(d, R);
+        if (dt > 0.0f) col = add(col, muls(muls(muls(mulv(Lc, s.Mc), pow20(dt)), s.ks), shade));
+    }
+    return col;
+}
+
+// (char)(clamp01(c)*255.0f) as the reference's Debug build evaluates it (main.cpp:139-142, 273):
+// truncate toward zero, keep the low byte; NaN passes the clamp and converts to the low byte of INT_MIN = 0.
+__device__ __forceinline__ uint8_t quantise8(float c)
+{
+    const float f = (c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c)) * 255.0f;
+    return (f == f) ? (uint8_t)(int)f : (uint8_t)0;
+}
+
 }  // namespace

@@ -1,5 +1,5 @@
 // rt_internal.h — device data layout and host-side plumbing shared by the
-// translation units of librt_amd.so (lbvh.hip, trace.hip, rt_shim.hip).
+// translation units of librt_amd.so (rt_shim.hip, trace.hip, wavefront.hip, shade.hip, lbvh.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -140,7 +140,7 @@ struct FrameParams {
     int timing;
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
     int wide_depth;                // depth of the 4-wide tree
-    int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages, 3 single traversal launch
+    int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages
     float *d_normal;               // optional device plane: the primary hit's normal, 3 floats per pixel (0 on a miss)
     float *d_uv;                   // optional device plane: the primary hit's texture coordinate, 2 floats per pixel
 };
@@ -165,9 +165,8 @@ struct FrameWorkspace {
     // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
     unsigned int *p_occ = nullptr; // [levels][chunks][pixels] occlusion bit per light, 32 lights per chunk
-    // single-launch pipeline (at most 32 lights)
-    float4 *ls_o = nullptr, *ls_d = nullptr;   // [waves][ls_entries] private ray stacks
-    size_t p_cap = 0, ls_cap = 0;  // elements allocated in p_hits / p_occ and in ls_o / ls_d
+    size_t p_cap = 0;              // elements allocated in p_hits / p_occ
+    size_t records_cap = 0;        // float4 elements allocated in records
     // staging outputs for the host-buffer entry point
     uint8_t *out_rgb8 = nullptr; int32_t *out_id = nullptr; float *out_rgb32 = nullptr; float *out_normal = nullptr; float *out_uv = nullptr;
     size_t out_cap = 0;
@@ -189,26 +188,14 @@ size_t wavefront_cursor_words(int levels, int n_chunks);
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
                     const std::function<int()> &stamp, int *n_launches, std::string *err);
-// persistent.hip: local colour of every level, fold and outputs from the [level][pixel] hit and occlusion planes
+// shade.hip: local colour of every level, fold and outputs from the [level][pixel] hit and occlusion planes
 int shade_all_launch(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, const float2 *hits,
                      const unsigned int *occ, int n_chunks, float4 *records, FrameCounters *counters, void *d_rgb8, void *d_hit_id,
                      void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus, std::string *err);
-// persistent.hip: the LBVH pipeline with one traversal launch per frame (writes the outputs itself).
-int persistent_max_lights(void);
-int persistent_grid(int num_cus);
-size_t persistent_stack_entries(int n_lights);
-size_t persistent_overflow_ints(int num_cus);
-size_t persistent_cursor_words(void);
-int persistent_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
-                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
-                     const std::function<int()> &stamp, int *n_launches, std::string *err);
-// Which LBVH pipeline a frame uses: 1 fused, 2 staged, 3 single launch.
-inline int lbvh_pipeline(int option, int n_lights)
-{
-    if (option == 1) return 1;
-    if (option == 3 && n_lights <= 32) return 3;      // the single-launch pipeline keeps one occlusion word per hit
-    return 2;
-}
+// Which LBVH pipeline a frame uses: 1 fused (one kernel per bounce level), 2 staged (traversal / generation / shading).
+inline int lbvh_pipeline(int option, int /*n_lights*/) { return option == 1 ? 1 : 2; }
+// Levels up to which the staged pipeline's shading keeps a pixel's level colours in registers (no records plane).
+constexpr int SHADE_REG_LEVELS = 9;
 int device_num_cus(std::string *err);   // trace.hip: CU count of the current device (cached), < 0 on error
 int trace_deinterleave(const void *src, void *dst, int W, int H, int band_rows, int n_parts, int rows_per_part,
                        int bpp, hipStream_t stream);

@@ -167,7 +167,7 @@ void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
                      ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
-                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.ls_o, ws.ls_d, ws.fq_counts[0], ws.fq_counts[1] };
+                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -186,17 +186,15 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
     }
     // ray queues are indexed by slot (the frame padded to whole 8x8 tiles, rounded up to whole regions)
     const size_t qslots = wavefront_regions(slots > pixels ? slots : pixels) * 256;
-    if (qslots > ws.pixels_cap || levels > ws.levels_cap) {
-        size_t pc = qslots > ws.pixels_cap ? qslots : ws.pixels_cap;
-        int lc = levels > ws.levels_cap ? levels : ws.levels_cap;
-        void *old[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.fq_counts[0], ws.fq_counts[1] };
+    if (qslots > ws.pixels_cap) {
+        void *old[] = { ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.fq_counts[0], ws.fq_counts[1] };
         for (void *p : old)
             if (p) (void)hipFree(p);
-        ws.records = nullptr; ws.hit_t = nullptr; ws.fq_counts[0] = ws.fq_counts[1] = nullptr;
+        ws.hit_t = nullptr; ws.fq_counts[0] = ws.fq_counts[1] = nullptr;
         ws.queue_o[0] = ws.queue_o[1] = ws.queue_d[0] = ws.queue_d[1] = nullptr;
-        ws.pixels_cap = 0; ws.levels_cap = 0;
-        hipError_t e = hipMalloc((void **)&ws.records, sizeof(float4) * pc * (size_t)lc);
-        if (e == hipSuccess) e = hipMalloc((void **)&ws.hit_t, sizeof(float) * pc);
+        ws.pixels_cap = 0;
+        const size_t pc = qslots;
+        hipError_t e = hipMalloc((void **)&ws.hit_t, sizeof(float) * pc);
         for (int k = 0; k < 2 && e == hipSuccess; k++) {
             e = hipMalloc((void **)&ws.queue_o[k], sizeof(float4) * pc);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.queue_d[k], sizeof(float4) * pc);
@@ -204,7 +202,17 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         }
         if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("frame workspace: ") + hipGetErrorString(e));
         ws.pixels_cap = pc;
-        ws.levels_cap = lc;
+    }
+    if (levels > ws.levels_cap) ws.levels_cap = levels;
+    // The per-level colour records (16 bytes per pixel and level) are only read by the fused pipeline and by staged frames
+    // too deep for the shading kernel's registers: a 7680x4320 frame of 9 levels would otherwise hold 4.8 GB for nothing.
+    const bool need_records = pipe == 1 || levels > SHADE_REG_LEVELS;
+    const size_t rec = need_records ? pixels * (size_t)levels : 0;
+    if (rec > ws.records_cap) {
+        if (ws.records) (void)hipFree(ws.records);
+        ws.records = nullptr; ws.records_cap = 0;
+        if (hipMalloc((void **)&ws.records, sizeof(float4) * rec) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(level records) failed");
+        ws.records_cap = rec;
     }
     if (wavefront) {
         // slot space: the frame padded to whole 8x8 tiles (>= pixels, also bounds every ray queue)
@@ -247,7 +255,7 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             ws.overflow_cap = ovf;
         }
     }
-    if (pipe == 2 || pipe == 3) {
+    if (pipe == 2) {
         // [level][pixel] hits and [level][chunk][pixel] occlusion words
         const size_t n_chunks = (size_t)((c->n_lights + 31) / 32 > 0 ? (c->n_lights + 31) / 32 : 1);
         const size_t need = pixels * (size_t)levels * n_chunks;
@@ -260,37 +268,6 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             if (e == hipSuccess) e = hipMalloc((void **)&ws.p_occ, sizeof(unsigned int) * need);
             if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("hit planes: ") + hipGetErrorString(e));
             ws.p_cap = need;
-        }
-    }
-    if (pipe == 3) {
-        std::string err;
-        const int cus = device_num_cus(&err);
-        if (cus <= 0) return fail(RT_E_DEVICE, err);
-        const size_t ls = persistent_stack_entries(c->n_lights) * (size_t)persistent_grid(cus) * 4;
-        if (ls > ws.ls_cap) {
-            if (ws.ls_o) (void)hipFree(ws.ls_o);
-            if (ws.ls_d) (void)hipFree(ws.ls_d);
-            ws.ls_o = ws.ls_d = nullptr; ws.ls_cap = 0;
-            hipError_t e = hipMalloc((void **)&ws.ls_o, sizeof(float4) * ls);
-            if (e == hipSuccess) e = hipMalloc((void **)&ws.ls_d, sizeof(float4) * ls);
-            if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("private ray stacks: ") + hipGetErrorString(e));
-            ws.ls_cap = ls;
-        }
-        const size_t ctr = persistent_cursor_words();
-        if (ctr > ws.cursors_cap) {
-            if (ws.trace_cursors) (void)hipFree(ws.trace_cursors);
-            ws.trace_cursors = nullptr; ws.cursors_cap = 0;
-            if (hipMalloc((void **)&ws.trace_cursors, sizeof(unsigned int) * ctr) != hipSuccess)
-                return fail(RT_E_NOMEM, "hipMalloc(claim cursors) failed");
-            ws.cursors_cap = ctr;
-        }
-        const size_t ovf = persistent_overflow_ints(cus);
-        if (ovf > ws.overflow_cap) {
-            if (ws.overflow) (void)hipFree(ws.overflow);
-            ws.overflow = nullptr; ws.overflow_cap = 0;
-            if (hipMalloc((void **)&ws.overflow, sizeof(int) * ovf) != hipSuccess)
-                return fail(RT_E_NOMEM, "hipMalloc(stack overflow columns) failed");
-            ws.overflow_cap = ovf;
         }
     }
     if (host_outputs && pixels > ws.out_cap) {
@@ -414,14 +391,14 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         // The launches of a frame depend only on these values: when none changed since the last frame,
         // replay the captured graph instead of issuing a dozen launches one by one.
         struct Key {
-            FrameParams fp; DevScene sc; DevCamera cam; void *out[4]; void *ws[18]; unsigned long long version;
+            FrameParams fp; DevScene sc; DevCamera cam; void *out[4]; void *ws[16]; unsigned long long version;
         } key;
         memset(&key, 0, sizeof key);
         key.fp = fp; key.sc = sc; key.cam = c->cam;
         key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
-        void *wsp[18] = { c->ws.records, c->ws.queue_o[0], c->ws.queue_o[1], c->ws.queue_d[0], c->ws.queue_d[1], c->ws.counters,
+        void *wsp[16] = { c->ws.records, c->ws.queue_o[0], c->ws.queue_o[1], c->ws.queue_d[0], c->ws.queue_d[1], c->ws.counters,
                           c->ws.p_hits, c->ws.p_occ, c->ws.sq_o, c->ws.sq_d, c->ws.trace_cursors, c->ws.overflow,
-                          c->ws.rq_counts[0], c->ws.rq_counts[1], c->ws.sq_counts, c->ws.ls_o, c->ws.ls_d, c->ws.hit_t };
+                          c->ws.rq_counts[0], c->ws.rq_counts[1], c->ws.sq_counts, c->ws.hit_t };
         memcpy(key.ws, wsp, sizeof wsp);
         key.version = c->state_version;
         const bool same = c->graph_exec && c->graph_key.size() == sizeof key && memcmp(c->graph_key.data(), &key, sizeof key) == 0;
@@ -564,7 +541,7 @@ int rt_set_option(rt_ctx *c, int option, int value)
         return RT_OK;
     case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graph(c); return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 3) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0..3");
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
         c->opt_pipeline = value;
         return RT_OK;
     default: return fail(RT_E_INVALID, "unknown option");

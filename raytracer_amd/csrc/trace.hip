@@ -217,34 +217,20 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             brute_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
         }
 
-        // ---- surface
+        // ---- surface (main.cpp:163-164)
         const bool hit = live && best_id >= 0;
-        F3 pos = mk(0.f, 0.f, 0.f), N = mk(0.f, 0.f, 1.f), Mc = mk(0.f, 0.f, 0.f);
-        float kr = 0.f, kd = 0.f, ks = 0.f;
-        bool emissive = false;
+        F3 pos = mk(0.f, 0.f, 0.f);
+        Surface s;
+        s.N = mk(0.f, 0.f, 1.f); s.Mc = mk(0.f, 0.f, 0.f); s.kr = 0.f; s.kd = 0.f; s.ks = 0.f; s.emissive = false;
         if (hit) {
             pos = add(o, muls(d, best_t));                                      // main.cpp:163
-            if (best_id < sc.n_analytic) {
-                const DevAnalytic a = sc.analytic[best_id];
-                N = (a.kind == RT_SPHERE) ? normalize(sub(pos, mk(a.px, a.py, a.pz)))   // main.cpp:72
-                                          : mk(a.px, a.py, a.pz);                       // main.cpp:96
-                Mc = mk(a.cr, a.cg, a.cb);
-                kr = a.reflect; kd = a.diffuse; ks = a.spec;
-                emissive = a.is_light != 0;
-            } else {
-                float4 tn = sc.tri_n[best_id - sc.n_analytic];                  // main.cpp:133
-                N = f3(tn);
-                if (sc.tri_vn) N = smooth_normal(sc, best_id - sc.n_analytic, o, d, N);
-                const DevMaterial m = sc.mats[__float_as_int(tn.w)];
-                Mc = mk(m.cr, m.cg, m.cb);
-                kr = m.reflect; kd = m.diffuse; ks = m.spec;
-            }
+            s = surface_at(sc, best_id, pos, o, d);                             // main.cpp:164
         }
 
         // ---- local shading (main.cpp:166-205)
         F3 col = mk(0.f, 0.f, 0.f);
-        const bool lit = hit && !emissive;
-        if (hit && emissive) col = Mc;                                          // main.cpp:166-167
+        const bool lit = hit && !s.emissive;
+        if (hit && s.emissive) col = s.Mc;                                      // main.cpp:166-167
         for (int li = 0; li < sc.n_lights; li++) {                              // main.cpp:170-173
             const DevAnalytic lt = sc.analytic[sc.lights[li]];
             F3 L = mk(0.f, 0.f, 1.f), so = pos;
@@ -260,20 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             } else if (lit && !occ) {
                 occ = brute_occluded<COUNT>(sc, so, L, tl);
             }
-            if (lit) {
-                const float shade = occ ? 0.0f : 1.0f;                          // main.cpp:175, 185
-                const F3 Lc = mk(lt.cr, lt.cg, lt.cb);
-                if (kd > 0.0f) {                                                // main.cpp:191-195
-                    float diffuse = dot(N, L) * kd;
-                    col = add(col, muls(muls(mulv(Lc, Mc), diffuse), shade));
-                }
-                if (ks > 0.0f) {                                                // main.cpp:198-204
-                    F3 R = sub(L, muls(muls(N, dot(L, N)), 2.0f));
-                    float dt = dot(d, R);
-                    if (dt > 0.0f)
-                        col = add(col, muls(muls(muls(mulv(Lc, Mc), pow20(dt)), ks), shade));
-                }
-            }
+            if (lit) col = add_light(col, s, L, mk(lt.cr, lt.cg, lt.cb), d, occ ? 0.0f : 1.0f);   // main.cpp:175, 185, 191-204
         }
 
         // ---- record + reflection ray (main.cpp:208-211)
@@ -282,7 +255,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
                 make_float4(col.x, col.y, col.z, __int_as_float(best_id));
             if (PRIMARY && A.hit_t) A.hit_t[pixel] = best_t;
             if (PRIMARY && A.normal) {
-                const F3 Nn = hit ? N : mk(0.f, 0.f, 0.f);
+                const F3 Nn = hit ? s.N : mk(0.f, 0.f, 0.f);
                 A.normal[3 * (size_t)pixel] = Nn.x; A.normal[3 * (size_t)pixel + 1] = Nn.y; A.normal[3 * (size_t)pixel + 2] = Nn.z;
             }
             if (PRIMARY && A.uv) {
@@ -290,10 +263,10 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
                 A.uv[2 * (size_t)pixel] = tc.x; A.uv[2 * (size_t)pixel + 1] = tc.y;
             }
         }
-        const bool spawn = lit && kr > 0.0f && more;
+        const bool spawn = lit && s.kr > 0.0f && more;
         const unsigned long long mask = __ballot(spawn);
         if (spawn) {
-            F3 R = sub(d, muls(muls(N, 2.0f), dot(d, N)));                      // main.cpp:210
+            const F3 R = mirror_dir(d, s.N);                                    // main.cpp:210
             const unsigned int dst = batch * 64u + (unsigned)__popcll(mask & lanemask_lt());
             A.q_out_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(pixel));       // origin is pos itself
             A.q_out_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
@@ -323,16 +296,6 @@ struct ResolveArgs {
     float *rgb32;       // may be null
     FrameCounters *counters;
 };
-
-__device__ __forceinline__ float clamp01(float f) { return f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f); }   // main.cpp:139-142
-
-// (char)(clamp01(c)*255.0f) as the reference's Debug build evaluates it (main.cpp:273):
-// truncate toward zero, keep the low byte; NaN converts to the low byte of INT_MIN = 0.
-__device__ __forceinline__ uint8_t quantise(float c)
-{
-    float f = clamp01(c) * 255.0f;
-    return (f == f) ? (uint8_t)(int)f : (uint8_t)0;
-}
 
 __global__ __launch_bounds__(BLOCK) void k_resolve(ResolveArgs A)
 {
@@ -380,9 +343,9 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(ResolveArgs A)
         }
         if (A.rgb32) { A.rgb32[3 * p] = col.x; A.rgb32[3 * p + 1] = col.y; A.rgb32[3 * p + 2] = col.z; }
         if (A.rgb8) {                                                               // main.cpp:273
-            A.rgb8[3 * p] = quantise(col.x);
-            A.rgb8[3 * p + 1] = quantise(col.y);
-            A.rgb8[3 * p + 2] = quantise(col.z);
+            A.rgb8[3 * p] = quantise8(col.x);
+            A.rgb8[3 * p + 1] = quantise8(col.y);
+            A.rgb8[3 * p + 2] = quantise8(col.z);
         }
         if (A.hit_id) A.hit_id[p] = id0;
     }
@@ -488,14 +451,6 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     if (int rc = stamp()) return rc;
     const int pipe = scene.accel == 1 ? lbvh_pipeline(fp.pipeline, scene.n_lights) : 1;
     const bool wavefront = pipe == 2;
-    if (pipe == 3) {
-        std::function<int()> st = stamp;
-        if (int rc = persistent_frame(scene, cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, g_num_cus, st, &launches, err))
-            return rc;
-        ws.n_events = (int)ev;
-        if (n_launches) *n_launches = launches;
-        return RT_OK;
-    }
     if (wavefront) {
         std::function<int()> st = stamp;
         if (int rc = wavefront_frame(scene, cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, g_num_cus, st, &launches, err))

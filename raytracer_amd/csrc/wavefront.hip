@@ -12,7 +12,7 @@
 //                    (main.cpp:178-188), survivors into one queue segment per light
 //     k_trace<mixed> ONE launch for the shadow rays of level k (any triangle at any distance
 //                    -> occlusion bit) and the nearest hits of level k+1: neither needs the other
-//   k_shade_all      (persistent.hip) per pixel: every level's local colour in the reference's
+//   k_shade_all      (shade.hip) per pixel: every level's local colour in the reference's
 //                    accumulation order (main.cpp:166-205), the fold, clamp and quantise
 //
 // Hits and occlusion bits live in planes indexed [level][pixel], so nothing has to be shaded
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             if (lit && A.level < A.max_depth) {
                 const Surface s = surface_at(sc, r.id, pos, r.o, r.d);                             // main.cpp:164
                 spawn = s.kr > 0.0f;                                                      // main.cpp:208
-                if (spawn) R = sub(r.d, muls(muls(s.N, 2.0f), dot(r.d, s.N)));            // main.cpp:210
+                if (spawn) R = mirror_dir(r.d, s.N);                                      // main.cpp:210
             }
             unsigned int total;
 #if WF_OCTSORT

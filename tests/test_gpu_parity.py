@@ -314,7 +314,7 @@ def test_tiny_meshes_through_every_hierarchy_shape(n_tris):
     assert_parity(compare(base, to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam))))
     for builder in (rt.BUILDER_LBVH, rt.BUILDER_PLOC):
         for leaf_max in (1, 2, 8):
-            for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_PERSISTENT):
+            for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT):
                 with rt.Context(0) as ctx:
                     ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
                     ctx.set_option(rt.OPT_BUILDER, builder)
@@ -430,7 +430,7 @@ def _smooth_scene():
 
 
 @pytest.mark.parametrize("accel,pipeline", [(rt.ACCEL_LINEAR, 0), (rt.ACCEL_LBVH, rt.PIPELINE_FUSED),
-                                            (rt.ACCEL_LBVH, rt.PIPELINE_WAVEFRONT), (rt.ACCEL_LBVH, rt.PIPELINE_PERSISTENT)])
+                                            (rt.ACCEL_LBVH, rt.PIPELINE_WAVEFRONT)])
 def test_shading_normals_match_the_oracle_rule_in_every_pipeline(accel, pipeline):
     """rt_set_triangle_normals: normals interpolated with Triangle::Raycast's own u, v.  The reference has
     no such feature (parity unpinned); the check is against the oracle's statement of the same rule, to
@@ -842,39 +842,28 @@ def test_light_counts_across_the_32_light_chunks(n_lights):
     assert rays(g["stats"]) == orays(r)
 
 
-def test_fused_staged_and_single_launch_pipelines_agree_bit_for_bit():
+def test_fused_and_staged_pipelines_agree_bit_for_bit():
+    """The one-kernel-per-level pipeline and the staged pipeline share their arithmetic (rt_device.h): same bytes,
+    same ray counts, at a depth the shading kernel holds in registers and at one it walks through the records
+    plane (more than 9 levels)."""
     spec = atrium_spec(detail=0.02)
     cam = rt.camera_for_width(320)
-    outs, stats = [], []
-    for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_PERSISTENT):
-        with rt.Context(0) as ctx:
-            ctx.set_option(rt.OPT_PIPELINE, pipeline)
-            to_product(ctx, spec)
-            ctx.set_camera(cam)
-            outs.append(ctx.render_frame(320, 180, max_depth=4))
-            stats.append(ctx.stats())
-    for other in outs[1:]:
-        for k in ("rgb8", "hit_id", "rgb32", "hit_t"):
-            if k in outs[0] and outs[0][k] is not None:
-                assert np.array_equal(outs[0][k].view(np.uint8), other[k].view(np.uint8)), k
-    for st in stats[1:]:
-        assert (st["rays_shadow"], st["rays_reflect"]) == (stats[0]["rays_shadow"], stats[0]["rays_reflect"])
-    assert stats[2]["n_launches"] == 2 and stats[1]["n_launches"] > 10
-
-
-def test_single_launch_pipeline_matches_the_oracle_on_golden_scenes():
-    for name, (spec, W, H, bounces, cam) in golden_cases().items():
-        if spec.n_tris < 2:
-            continue
-        with rt.Context(0) as ctx:
-            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
-            ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_PERSISTENT)
-            to_product(ctx, spec)
-            ctx.set_camera(cam)
-            g = ctx.render_frame(W, H, max_depth=bounces)
-            g["stats"] = ctx.stats()
-        r = to_oracle(spec).render(W, H, max_depth=bounces, cam=ocam(cam))
-        assert_parity(compare(g, r)), name
+    for depth in (4, 11):
+        outs, stats = [], []
+        for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT):
+            with rt.Context(0) as ctx:
+                ctx.set_option(rt.OPT_PIPELINE, pipeline)
+                to_product(ctx, spec)
+                ctx.set_camera(cam)
+                outs.append(ctx.render_frame(320, 180, max_depth=depth))
+                stats.append(ctx.stats())
+        for k in ("rgb8", "hit_id", "rgb32"):
+            assert np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8)), (k, depth)
+        assert rays(stats[0]) == rays(stats[1])
+        assert stats[0]["n_launches"] == depth + 2 and stats[1]["n_launches"] > 2 * depth
+    with rt.Context(0) as ctx:
+        with pytest.raises(rt.RtError):
+            ctx.set_option(rt.OPT_PIPELINE, 3)
 
 
 def test_partitioned_renderer_is_ordered_by_streams_alone():
