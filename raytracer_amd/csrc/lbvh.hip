@@ -689,7 +689,7 @@ __global__ void k_pre_level(const int2 *__restrict__ children, const int *__rest
 __device__ __forceinline__ int emit_node(int i, const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
                        const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre,
-                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid)
+                       BvhNode *nodes, QuantGrid *grid)
 {
     if (i >= n - 1) return 0;
     // 15-bit lattice over the root box (the union of all padded leaf boxes)
@@ -728,25 +728,6 @@ __device__ __forceinline__ int emit_node(int i, const int2 *__restrict__ childre
     nd.z01 = make_float4(l0.z, h0.z, l1.z, h1.z);
     nd.ch = make_int4(enc[0], enc[1], 0, 0);
     nodes[pre[i]] = nd;
-    // The same two boxes rounded OUTWARD onto the lattice: base + q*step <= lo and >= hi (computed in
-    // double so the floor/ceil are exact), 32 bytes per node instead of 64.
-    const float lo[2][3] = { { l0.x, l0.y, l0.z }, { l1.x, l1.y, l1.z } }, hi[2][3] = { { h0.x, h0.y, h0.z }, { h1.x, h1.y, h1.z } };
-    unsigned int w[6];
-    for (int c2 = 0; c2 < 2; c2++) {
-        for (int k = 0; k < 3; k++) {
-            double ql = floor(((double)lo[c2][k] - (double)gb[k]) / (double)gs[k]);
-            double qh = ceil(((double)hi[c2][k] - (double)gb[k]) / (double)gs[k]);
-            ql = fmin(fmax(ql, 0.0), 32767.0);
-            qh = fmin(fmax(qh, 0.0), 32767.0);
-            // bit 15 of each half is always set: placed in bytes 1-2 under an exponent byte 0x3f the half
-            // reads as the float 1 + q/32768, so the traversal needs no integer-to-float conversion
-            w[c2 * 3 + k] = (0x8000u | (unsigned int)ql) | ((0x8000u | (unsigned int)qh) << 16);
-        }
-    }
-    BvhNodeQ qn;
-    qn.a = make_uint4(w[0], w[1], w[2], w[3]);
-    qn.b = make_uint4(w[4], w[5], (unsigned int)enc[0], (unsigned int)enc[1]);
-    qnodes[pre[i]] = qn;
     return depth[i] + 1;
 }
 
@@ -754,10 +735,10 @@ __device__ __forceinline__ int emit_node(int i, const int2 *__restrict__ childre
 __global__ void k_emit(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
                        const int *__restrict__ depth, int n, int leaf_max, const float4 *__restrict__ box_lo,
                        const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre,
-                       BvhNode *nodes, BvhNodeQ *qnodes, QuantGrid *grid, int *live_depth)
+                       BvhNode *nodes, QuantGrid *grid, int *live_depth)
 {
     int d = emit_node(blockIdx.x * blockDim.x + threadIdx.x, children, range, parent, depth, n, leaf_max, box_lo, box_hi, leafpos, pre,
-                      nodes, qnodes, grid);
+                      nodes, grid);
     for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
     if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(live_depth, d);
 }
@@ -1028,7 +1009,6 @@ int tri_setup_indexed(const float *d_verts, int n_verts, const int32_t *d_indice
 void lbvh_free(LbvhResult *r)
 {
     if (r->nodes) (void)hipFree(r->nodes);
-    if (r->qnodes) (void)hipFree(r->qnodes);
     if (r->wnodes) (void)hipFree(r->wnodes);
     if (r->bvh_tri) (void)hipFree(r->bvh_tri);
     delete r->topo;
@@ -1179,7 +1159,6 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     A(scan_u32.alloc((size_t)blocks_for(256 * n_tiles, 4096) + 1));
     A(scan_u64.alloc((size_t)blocks_for(n, 4096) + 1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
-    A(hipMalloc((void **)&out->qnodes, sizeof(BvhNodeQ) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES)));
     A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
     if (e != hipSuccess) {
@@ -1200,7 +1179,6 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     }
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
-    RT_HIP_CHECK(hipMemsetAsync(out->qnodes, 0, sizeof(BvhNodeQ) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
     const bool ploc = builder != 1;
     int max_depth = 0;
@@ -1271,7 +1249,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     for (int level = 0; level <= max_depth; level++)
         hipLaunchKernelGGL(k_pre_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n, level, live.p, pre.p);
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
-                       leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes, out->qnodes,
+                       leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes,
                        grid.p, scalars.p + 1);
     DevBuf<int> wide, pre4, root, slot;
     DevBuf<int4> wkids;
@@ -1360,7 +1338,7 @@ int lbvh_refit(const float4 *tri_mt, int n_tris, hipStream_t stream, LbvhResult 
     for (int level = t->max_depth; level >= 0; level--)
         hipLaunchKernelGGL(k_refit_level, dim3(GI), dim3(B), 0, stream, t->children, t->depth, n - 1, level, t->box_lo, t->box_hi);
     hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->parent, t->depth, n, out->leaf_max,
-                       t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, out->qnodes, t->grid, t->scalars + 1);
+                       t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, t->grid, t->scalars + 1);
     hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->range, t->live, t->root, t->wkids, n, out->leaf_max, t->box_lo,
                        t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->ref_tri, t->vals, t->ploc ? t->order : (const int *)nullptr, n,

@@ -42,14 +42,8 @@ struct BvhNode {
     int4 ch;      // child0, child1, unused, unused
 };
 
-// The same node with its boxes rounded outward onto a 15-bit lattice over the root box, 32 B
-// (each 16-bit half is 0x8000 | q): world = base + q * step per axis (QuantGrid).  Half the bytes per traversal step.
-struct BvhNodeQ {
-    uint4 a;      // child0 x (lo | hi << 16), child0 y, child0 z, child1 x
-    uint4 b;      // child1 y, child1 z, child0 ref, child1 ref
-};
-
-// Four children per node on the same lattice, 64 B: one dependent fetch where the binary tree needs two.
+// Four children per node, 64 B, boxes rounded outward onto a 15-bit lattice over the root box (each 16-bit half of a
+// word is 0x8000 | q; world = base + q * step per axis, QuantGrid): one dependent fetch where the binary tree needs two.
 // An unused slot holds an inverted box (never entered).
 struct BvhNode4 {
     uint4 a;      // child0 x, y, z, child1 x          (each word lo | hi << 16)
@@ -77,7 +71,6 @@ struct DevScene {
     const float2 *tri_vt;          // [n_tris*3] texture coordinates at v1, v2, v3, or null (only the uv plane reads them)
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
-    const BvhNodeQ *qnodes;        // same tree, quantised boxes
     const BvhNode4 *wnodes;        // the tree collapsed to four children per node
     QuantGrid grid;
     const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
@@ -110,7 +103,6 @@ struct LbvhTopology;   // lbvh.hip: what the build keeps so that lbvh_refit can 
 struct LbvhResult {
     LbvhTopology *topo = nullptr;
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
-    BvhNodeQ *qnodes = nullptr;    // [max(n_tris-1,1)]
     BvhNode4 *wnodes = nullptr;    // [WIDE_TOP_NODES + max(n_tris-1,1)] (about a quarter used)
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]

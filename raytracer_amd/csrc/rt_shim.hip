@@ -341,7 +341,7 @@ DevScene device_scene(const rt_ctx *c, int accel)
     DevScene sc;
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
     sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.nodes = c->bvh.nodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
     sc.n_refs = c->bvh.n_refs;
     return sc;

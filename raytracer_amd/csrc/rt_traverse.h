@@ -46,22 +46,4 @@ __device__ __forceinline__ void slab_ray(const QuantGrid &g, F3 o, F3 d, F3 &inv
     oi_out = mk(oi.x - inv.x, oi.y - inv.y, oi.z - inv.z);
 }
 
-// Both children of one 32-byte node against the ray interval [0, tmax]: entry parameters and hit flags.
-__device__ __forceinline__ void node_test(const uint4 qa, const uint4 qb, const F3 inv, const F3 oi, const uint3 sel_n,
-                                          const uint3 sel_f, float tmax, float &n0, float &n1, bool &h0, bool &h1)
-{
-    // The ray's direction signs decide which plane of each pair is entered first, so no min/max per
-    // axis; one v_perm_b32 per plane builds its float, and the two planes of a pair share a packed fma.
-    const V2 x0 = plane_pair(qa.x, sel_n.x, sel_f.x, inv.x, oi.x), y0 = plane_pair(qa.y, sel_n.y, sel_f.y, inv.y, oi.y),
-             z0 = plane_pair(qa.z, sel_n.z, sel_f.z, inv.z, oi.z);
-    const V2 x1 = plane_pair(qa.w, sel_n.x, sel_f.x, inv.x, oi.x), y1 = plane_pair(qb.x, sel_n.y, sel_f.y, inv.y, oi.y),
-             z1 = plane_pair(qb.y, sel_n.z, sel_f.z, inv.z, oi.z);
-    n0 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x0.x, y0.x), z0.x), 0.0f);
-    const float f0 = fminf(__builtin_fminf(__builtin_fminf(x0.y, y0.y), z0.y), tmax);
-    n1 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x1.x, y1.x), z1.x), 0.0f);
-    const float f1 = fminf(__builtin_fminf(__builtin_fminf(x1.y, y1.y), z1.y), tmax);
-    h0 = n0 <= f0;
-    h1 = n1 <= f1;
-}
-
 }  // namespace

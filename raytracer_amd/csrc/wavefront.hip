@@ -58,27 +58,11 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_UNIT
 #define WF_UNIT 64
 #endif
-#ifndef WF_WIDE
-#define WF_WIDE 1          // traverse the 4-wide nodes (one dependent fetch per two binary levels)
-#endif
-#ifndef WF_SORT
-#define WF_SORT 0          // 0: nearest child first, the other hits in slot order (measured 2 % faster); 1: all hits sorted by entry distance
-#endif
 #ifndef WF_CLOSEST_FIRST
 #define WF_CLOSEST_FIRST 1
 #endif
-#ifndef WF_TOP_CACHE
-#define WF_TOP_CACHE 0     // 1: keep the top levels of the wide tree in LDS (measured 5 % slower: two load paths per step)
-#endif
 #ifndef WF_MERGE
 #define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
-#endif
-#ifndef WF_IKEY
-#define WF_IKEY 1          // 1: hit flag and entry distance of a child in one signed integer key (see the node step)
-#endif
-#ifndef WF_AFFINE
-#define WF_AFFINE 0        // 1: a shard claims a contiguous range of regions (of every segment) instead of every n_shards-th unit,
-                           //    and the shards of one XCD (blocks b, b + 8, ... share one) hold neighbouring ranges
 #endif
 #ifndef WF_WAVES_EU
 #define WF_WAVES_EU 8      // register budget and resident blocks per CU of k_trace
@@ -132,20 +116,11 @@ void k_trace(TraceArgs A)
 {
     constexpr bool ANYHIT = MODE == 1;
     __shared__ int s_stack[WF_LDS_STACK * BLOCK];
-#if WF_WIDE && WF_TOP_CACHE
-    // the top levels of the wide tree, copied once per block: every ray starts here, and the vector
-    // memory return path (not LDS) is what limits this kernel
-    __shared__ uint4 s_top[WIDE_TOP_NODES * 4];
-#endif
     const int lane = threadIdx.x & 63;
     int *stack = s_stack + threadIdx.x;                                   // element k at stack[k * BLOCK]
     int *ovf = A.overflow + (size_t)blockIdx.x * BLOCK + threadIdx.x;     // element k at ovf[k * total_lanes]
     const DevScene &sc = A.sc;
     const unsigned long long lt = lanemask_lt();
-#if WF_WIDE && WF_TOP_CACHE
-    for (int k = threadIdx.x; k < WIDE_TOP_NODES * 4; k += BLOCK) s_top[k] = ((const uint4 *)sc.wnodes)[k];
-    __syncthreads();
-#endif
 
     // ---- per-lane ray state
     int node = NODE_SENTINEL, sp = 0, tri_i = 0, tri_left = 0, best_id = -1, bit = MODE == 0 ? -1 : 0;
@@ -162,17 +137,9 @@ void k_trace(TraceArgs A)
     // Every shard needs an owner that drains it to the end: with fewer blocks than SHARDS only
     // gridDim.x shards are used.
     const int n_shards = (int)min((unsigned)SHARDS, gridDim.x);
-    const int max_probes = min(WF_AFFINE ? 24 : MAX_PROBES, n_shards);
+    const int max_probes = min(MAX_PROBES, n_shards);
     int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
     const unsigned int n_units = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0)) * (unsigned)A.n_regions * UPR;
-#if WF_AFFINE
-    // units of one segment per shard, and the place of a shard's range: shards s, s + 8, ... run on one XCD
-    const unsigned int per_seg_u = (unsigned)A.n_regions * UPR, n_segs_u = (unsigned)(A.n_segments + (MODE == 2 ? 1 : 0));
-    const unsigned int per_shard = (per_seg_u + (unsigned)n_shards - 1) / (unsigned)n_shards;
-    auto range_of = [&](int sh) -> unsigned int {
-        return n_shards == SHARDS ? (unsigned)((sh & 7) * (SHARDS / 8) + (sh >> 3)) : (unsigned)sh;
-    };
-#endif
     bool exhausted = n_units == 0;
     unsigned long long t_start = 0, t_exhaust = 0;
     if ((COUNT || WF_TIMES) && A.wave_times) t_start = t_exhaust = wall_clock64();
@@ -206,37 +173,11 @@ void k_trace(TraceArgs A)
                 // units are dealt to shards round-robin (unit = k*n_shards + shard); a wave drains its own
                 // shard to the end, then steals from the next few
                 unsigned int k = 0;
-#if WF_AFFINE
-                // a shard that is not this wave's own is looked at before it is claimed from: most are already drained
-                if (probes > 0) {
-                    unsigned int seen = 0;
-                    if (lane == 0) seen = __hip_atomic_load(&A.cursors[shard * CURSOR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-                    if (seen >= n_segs_u * per_shard) {
-                        shard = n_shards == SHARDS ? (probes < 7 ? (shard + 8) % SHARDS : (shard + 1) % SHARDS) : (shard + 1 == n_shards ? 0 : shard + 1);
-                        if (++probes >= max_probes) exhausted = true;
-                        continue;
-                    }
-                }
-#endif
                 if (lane == 0) k = atomicAdd(&A.cursors[shard * CURSOR_STRIDE], 1u);
                 k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-#if WF_AFFINE
-                // the shard's k-th claim: unit (k % per_shard) of its range in segment k / per_shard
-                const unsigned int seg_k = k / per_shard, in_seg = range_of(shard) * per_shard + k % per_shard;
-                const bool past = seg_k >= n_segs_u;
-                if (!past && in_seg >= per_seg_u) continue;             // the last range is shorter
-                const unsigned long long unit = past ? (unsigned long long)n_units : (unsigned long long)seg_k * per_seg_u + in_seg;
-#else
                 const unsigned long long unit = (unsigned long long)k * (unsigned)n_shards + (unsigned)shard;
-#endif
                 if (unit >= n_units) {
-#if WF_AFFINE
-                    // steal from the shards of the same XCD first (they hold the neighbouring ranges)
-                    shard = n_shards == SHARDS ? (probes < 7 ? (shard + 8) % SHARDS : (shard + 1) % SHARDS) : (shard + 1 == n_shards ? 0 : shard + 1);
-#else
                     shard = shard + 1 == n_shards ? 0 : shard + 1;
-#endif
                     if (++probes >= max_probes) {
                         exhausted = true;
                         if ((COUNT || WF_TIMES) && A.wave_times) t_exhaust = wall_clock64();
@@ -312,25 +253,17 @@ void k_trace(TraceArgs A)
         if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); }
         if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
         if (do_node) {
-            // ---- inner-node step: both children's lattice boxes from one 32-byte node
+            // ---- inner-node step: four children per 64-byte node
             if ((unsigned)node < SENT_U) {
                 const float tmax = ANYHIT ? FLT_MAX : best_t;      // mixed: a shadow lane's best_t stays FLT_MAX
-#if WF_WIDE
                 // four children from one 64-byte node; the lattice boxes contain the padded float boxes
                 uint4 qa, qb, qc, qd;
-#if WF_TOP_CACHE
-                if (node < WIDE_TOP_NODES) {
-                    const uint4 *tp = s_top + 4 * node;
-                    qa = tp[0]; qb = tp[1]; qc = tp[2]; qd = tp[3];
-                } else
-#endif
                 {
                     // 32-bit byte offset from the uniform base: one shift instead of 64-bit address arithmetic
                     // (the builder keeps the wide node array below 4 GiB)
                     const uint4 *np = (const uint4 *)((const char *)sc.wnodes + (unsigned)RTG(node, A.n_wnodes) * 64u);
                     qa = np[0]; qb = np[1]; qc = np[2]; qd = np[3];
                 }
-#if WF_IKEY
                 // Entry distance and hit flag of each child in ONE integer key: the bits of the (non-negative) entry
                 // distance, with the sign bit set when the box is hit, so that as signed integers hit children sort
                 // before missed ones and among themselves by distance.  The flag comes from the sign of far - near
@@ -382,89 +315,6 @@ void k_trace(TraceArgs A)
                     if (dk[1] < 0) push(rk[1]);
                     node = rk[0];
                 }
-#else
-                float dk[4];
-                int rk[4] = { (int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w };
-                {
-                    const unsigned int wx[4] = { qa.x, qa.w, qb.z, qc.y }, wy[4] = { qa.y, qb.x, qb.w, qc.z },
-                                       wz[4] = { qa.z, qb.y, qc.x, qc.w };
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const V2 x = plane_pair(wx[k], sel_n.x, sel_f.x, inv.x, oi.x), y = plane_pair(wy[k], sel_n.y, sel_f.y, inv.y, oi.y),
-                                 z = plane_pair(wz[k], sel_n.z, sel_f.z, inv.z, oi.z);
-                        const float nk = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), 0.0f);
-                        const float fk = fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), tmax);
-                        dk[k] = nk <= fk ? nk : FLT_MAX;           // entry distance, or "missed" (unused slots always miss)
-                    }
-                }
-                if (COUNT) tl.box += 4;
-                // nearest first: a five-exchange sorting network on (distance, reference)
-#define WF_CSWAP(a, b)                                                          \
-                {                                                               \
-                    const bool sw = dk[b] < dk[a];                              \
-                    const float td = sw ? dk[b] : dk[a];                        \
-                    const int tr = sw ? rk[b] : rk[a];                          \
-                    dk[b] = sw ? dk[a] : dk[b];                                 \
-                    rk[b] = sw ? rk[a] : rk[b];                                 \
-                    dk[a] = td;                                                 \
-                    rk[a] = tr;                                                 \
-                }
-#if WF_SORT
-                const int n_hit = (dk[0] < FLT_MAX) + (dk[1] < FLT_MAX) + (dk[2] < FLT_MAX) + (dk[3] < FLT_MAX);
-                WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2) WF_CSWAP(1, 3) WF_CSWAP(1, 2)
-#undef WF_CSWAP
-                if (n_hit == 0) {
-                    pop();
-                } else {
-                    if (n_hit > 3) push(rk[3]);
-                    if (n_hit > 2) push(rk[2]);
-                    if (n_hit > 1) push(rk[1]);
-                    node = rk[0];
-                }
-#else
-                // nearest child to slot 0; the other hits are pushed in slot order
-                WF_CSWAP(0, 1) WF_CSWAP(2, 3) WF_CSWAP(0, 2)
-#undef WF_CSWAP
-                if (!(dk[0] < FLT_MAX)) {
-                    pop();
-                } else if (sp + 3 <= WF_LDS_STACK) {
-                    // branch-free push: every slot is stored, a miss lands on the position the next
-                    // hit (or a later push) overwrites
-                    const int c3 = dk[3] < FLT_MAX ? 1 : 0, c2 = dk[2] < FLT_MAX ? 1 : 0, c1 = dk[1] < FLT_MAX ? 1 : 0;
-                    stack[sp * BLOCK] = rk[3];
-                    stack[(sp + c3) * BLOCK] = rk[2];
-                    stack[(sp + c3 + c2) * BLOCK] = rk[1];
-                    sp += c3 + c2 + c1;
-                    node = rk[0];
-                } else {
-                    if (dk[3] < FLT_MAX) push(rk[3]);
-                    if (dk[2] < FLT_MAX) push(rk[2]);
-                    if (dk[1] < FLT_MAX) push(rk[1]);
-                    node = rk[0];
-                }
-#endif
-#endif
-#else
-                // ---- both children's lattice boxes from one 32-byte node
-                const BvhNodeQ *np = sc.qnodes + node;
-                const uint4 qa = np->a, qb = np->b;
-                const int2 ch = make_int2((int)qb.z, (int)qb.w);
-                float n0, n1;
-                bool h0, h1;
-                node_test(qa, qb, inv, oi, sel_n, sel_f, tmax, n0, n1, h0, h1);
-                if (COUNT) tl.box += 2;
-                if (h0 && h1) {
-                    const bool swap = !ANYHIT && n1 < n0;
-                    push(swap ? ch.x : ch.y);
-                    node = swap ? ch.y : ch.x;
-                } else if (h0) {
-                    node = ch.x;
-                } else if (h1) {
-                    node = ch.y;
-                } else {
-                    pop();
-                }
-#endif
             }
         }
         if (do_leaf) {
@@ -602,40 +452,10 @@ __device__ __forceinline__ unsigned int block_rank(bool flag, unsigned int *s_cn
     return before + (unsigned)__popcll(mask & lanemask_lt());
 }
 
-#ifndef WF_OCTSORT
-#define WF_OCTSORT 0       // 1: the next level's rays of a region are written grouped by the octant of their direction
-#endif
-// Rank of this thread among the block's threads with `flag` set when those are ordered by (key, thread): a stable
-// counting sort on a 3-bit key.  s_tab: 8 * (BLOCK / 64) LDS words.  Two barriers; every thread must call it.
-__device__ __forceinline__ unsigned int block_rank_keyed(bool flag, unsigned int key, unsigned int *s_tab, unsigned int &total)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long mine = 0ull;
-    for (unsigned int k = 0; k < 8; k++) {
-        const unsigned long long m = __ballot(flag && key == k);
-        if ((unsigned)lane == k) s_tab[k * (BLOCK / 64) + wave] = (unsigned)__popcll(m);
-        if (key == k) mine = m;
-    }
-    __syncthreads();
-    unsigned int before = 0, all = 0;
-    for (unsigned int k = 0; k < 8; k++)
-        for (int w = 0; w < BLOCK / 64; w++) {
-            const unsigned int c = s_tab[k * (BLOCK / 64) + w];
-            if (k < key || (k == key && w < wave)) before += c;
-            all += c;
-        }
-    __syncthreads();
-    total = all;
-    return before + (unsigned)__popcll(mine & lanemask_lt());
-}
-
 template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
 {
     __shared__ unsigned int s_cnt[BLOCK / 64];
-#if WF_OCTSORT
-    __shared__ unsigned int s_tab[8 * (BLOCK / 64)];
-#endif
     const DevScene &sc = A.sc;
     Tally tl = { 0u, 0u, 0u };
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
@@ -657,12 +477,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
                 if (spawn) R = mirror_dir(r.d, s.N);                                      // main.cpp:210
             }
             unsigned int total;
-#if WF_OCTSORT
-            const unsigned int oct = (R.x < 0.0f ? 1u : 0u) | (R.y < 0.0f ? 2u : 0u) | (R.z < 0.0f ? 4u : 0u);
-            const unsigned int rank = block_rank_keyed(spawn, oct, s_tab, total);
-#else
             const unsigned int rank = block_rank(spawn, s_cnt, total);
-#endif
             if (spawn) {
                 const size_t dst = (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
@@ -735,7 +550,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     const int n_chunks = (scene.n_lights + 31) / 32;
     const int trace_grid = wavefront_trace_grid(num_cus);
     const bool count = fp.count_tests != 0;
-    if ((WF_WIDE ? 3 * fp.wide_depth + 1 : fp.stack_depth + 1) > WF_LDS_STACK + WF_OVF) {
+    if (3 * fp.wide_depth + 1 > WF_LDS_STACK + WF_OVF) {
         if (err) *err = "LBVH deeper than the traversal stack";
         return RT_E_LIMIT;
     }
