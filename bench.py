@@ -179,18 +179,20 @@ def main():
 
     # the timed loop runs without per-launch device events, so that an unchanged frame replays as one
     # hipGraph; kernel times come from one more frame with the events on, outside the timed region
+    # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
     ctx.set_option(rt.OPT_TIMING, 0)
-    for _ in range(a.warmup):
+    with torch.cuda.stream(pr.stream):
+        for _ in range(a.warmup):
+            pr.render()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            pr.render()
+        sync_all()
+        dt = time.perf_counter() - t0
+        ctx.set_option(rt.OPT_TIMING, 1)
         pr.render()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        pr.render()
-    sync_all()
-    dt = time.perf_counter() - t0
-    ctx.set_option(rt.OPT_TIMING, 1)
-    pr.render()
-    sync_all()
+        sync_all()
     st = ctx.stats()   # one frame of this rank: ray counts + device-event kernel times
 
     rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
@@ -206,6 +208,7 @@ def main():
     # device events the library records around those launches on the launch stream.
     ctx.set_option(rt.OPT_COUNT_TESTS, 1)
     pr.render()
+    sync_all()
     cst = ctx.stats()
     ctx.set_option(rt.OPT_COUNT_TESTS, 0)
     flops = cst["box_tests"] * FLOP_BOX + cst["tri_tests"] * FLOP_TRI + cst["analytic_tests"] * FLOP_ANALYTIC
@@ -244,7 +247,8 @@ def main():
             # the same frames with every launch issued one by one (a frame that changes cannot replay a graph)
             ctx.set_option(rt.OPT_TIMING, 0)
             ctx.set_option(rt.OPT_GRAPH, 0)
-            out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
+            with torch.cuda.stream(pr.stream):
+                out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
             ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
             if st["accel"]:
                 out["share_ms"] = share_table(ctx, wl, a.band_rows, torch, dev)
@@ -255,9 +259,10 @@ def main():
                     wl2.load(ctx2)
                     ctx2.set_option(rt.OPT_TIMING, 0)
                     pr2 = PartitionedRenderer(ctx2, wl2.W, wl2.H, wl2.max_depth, 0, 1, a.band_rows, dev)
-                    ms2 = timed_frames(pr2.render, sync_all, a.steps, a.warmup)
-                    ctx2.set_option(rt.OPT_TIMING, 1)
-                    pr2.render(); sync_all()
+                    with torch.cuda.stream(pr2.stream):
+                        ms2 = timed_frames(pr2.render, sync_all, a.steps, a.warmup)
+                        ctx2.set_option(rt.OPT_TIMING, 1)
+                        pr2.render(); sync_all()
                     s2 = ctx2.stats()
                 r2 = s2["rays_primary"] + s2["rays_shadow"] + s2["rays_reflect"]
                 out["other_workloads"] = {wl2.name: {"value": r2 / ms2 / 1e3, "unit": "Mrays/s", "ms_per_step": ms2,

@@ -113,6 +113,8 @@ class PartitionedRenderer:
             return self._frame()
         torch = self.torch
         caller = torch.cuda.current_stream(self.device)
+        if caller.cuda_stream == self.stream.cuda_stream:      # the caller already works on this object's stream: nothing to order
+            return self._frame()
         self.stream.wait_stream(caller)          # earlier readers/writers of our buffers on the caller's stream come first
         with torch.cuda.stream(self.stream):
             out = self._frame()
