@@ -91,6 +91,7 @@ struct FrameCounters {
     unsigned long long box_tests, tri_tests, analytic_tests;
     // RT_OPT_COUNT_TESTS only: wave iterations of each traversal step and the lanes that took part
     unsigned long long node_iters, node_lanes, leaf_iters, leaf_lanes, refill_events, refill_lanes;
+    unsigned long long node_idle, node_leafwait;   // lanes that sat out the node steps: without a ray / waiting at a leaf
     unsigned long long step_hist[16];             // rays by traversal steps taken: bin = bit length of the step count
     unsigned int max_steps, pad_steps;
     unsigned int guard_hits, pad_guard;          // RT_GUARD builds: indices found outside their array (0 otherwise)

@@ -1033,8 +1033,9 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->tri_tests = fc.tri_tests;
     out->analytic_tests = fc.analytic_tests;
     if (c->opt_count && getenv("RT_WF_DEBUG") && fc.node_iters)
-        fprintf(stderr, "[rt] traversal: node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes), refills %llu (%.1f rays)\n",
-                fc.node_iters, (double)fc.node_lanes / (double)fc.node_iters, fc.leaf_iters,
+        fprintf(stderr, "[rt] traversal: node steps %llu (%.1f lanes; %.1f without a ray, %.1f waiting at a leaf), leaf steps %llu (%.1f lanes), refills %llu (%.1f rays)\n",
+                fc.node_iters, (double)fc.node_lanes / (double)fc.node_iters, (double)fc.node_idle / (double)fc.node_iters,
+                (double)fc.node_leafwait / (double)fc.node_iters, fc.leaf_iters,
                 fc.leaf_iters ? (double)fc.leaf_lanes / (double)fc.leaf_iters : 0.0, fc.refill_events,
                 fc.refill_events ? (double)fc.refill_lanes / (double)fc.refill_events : 0.0);
     if (c->opt_count && getenv("RT_WF_DEBUG") && fc.max_steps) {

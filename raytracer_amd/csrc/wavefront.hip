@@ -129,7 +129,7 @@ void k_trace(TraceArgs A)
     uint3 sel_n = make_uint3(SEL_LO, SEL_LO, SEL_LO), sel_f = make_uint3(SEL_HI, SEL_HI, SEL_HI);
     float best_t = FLT_MAX;
     Tally tl = { 0u, 0u, 0u };
-    unsigned int dbg[6] = { 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes
+    unsigned int dbg[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes, idle / leaf-waiting lanes at node steps
 
     // ---- per-wave fetch state (uniform): local range [cur, end) of queue positions in segment `seg`
     unsigned int cur = 0, end = 0;
@@ -250,7 +250,7 @@ void k_trace(TraceArgs A)
         // the step more lanes are waiting for
         const bool do_node = (int)__popcll(m_node) >= (int)__popcll(m_leaf);
         const bool do_leaf = !do_node;
-        if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); }
+        if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); dbg[6] += 64u - (unsigned)__popcll(m_node | m_leaf); dbg[7] += (unsigned)__popcll(m_leaf); }
         if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
         if (do_node) {
             // ---- inner-node step: four children per 64-byte node
@@ -366,7 +366,7 @@ void k_trace(TraceArgs A)
         }
         if (lane == 0) {
             unsigned long long *dst = &A.counters->node_iters;
-            for (int k = 0; k < 6; k++)
+            for (int k = 0; k < 8; k++)
                 if (dbg[k]) atomicAdd(dst + k, (unsigned long long)dbg[k]);
         }
     }
