@@ -143,7 +143,8 @@ struct FrameWorkspace {
     float *hit_t = nullptr;        // [n_pixels] level-0 nearest t
     float4 *queue_o[2] = { nullptr, nullptr };   // ray queues: (origin, pixel index bits)
     float4 *queue_d[2] = { nullptr, nullptr };   //             (direction, unused)
-    FrameCounters *counters = nullptr;
+    FrameCounters *counters = nullptr;   // head of the block that one memset clears per frame; the claim cursors follow it
+    size_t zero_cap = 0;                 // bytes allocated in that block
     size_t pixels_cap = 0;
     int levels_cap = 0;
     // wavefront pipeline (LBVH scenes)
@@ -151,9 +152,9 @@ struct FrameWorkspace {
     unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue
     unsigned int *fq_counts[2] = { nullptr, nullptr };   // fused kernel: rays per 64-slot batch of each ray queue
     unsigned int *sq_counts = nullptr;         // [seg_cap][regions] shadow rays per segment and region
-    unsigned int *trace_cursors = nullptr;     // per-frame unit claim cursors, one row per k_trace launch
+    unsigned int *trace_cursors = nullptr;     // per-frame unit claim cursors, one row per k_trace launch (inside the counters' block)
     int *overflow = nullptr;       // traversal stack spill columns
-    size_t slots_cap = 0, overflow_cap = 0, cursors_cap = 0;
+    size_t slots_cap = 0, overflow_cap = 0;
     int chunks_cap = 0, seg_cap = 0;
     // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
@@ -168,6 +169,9 @@ struct FrameWorkspace {
     std::vector<hipEvent_t> trav_events;   // begin/end pairs around the traversal launches of the last frame
     int trav_pairs = 0;
 };
+
+// Bytes from the frame counters to the claim cursors that share their allocation (and their per-frame memset).
+constexpr size_t COUNTERS_PAD = (sizeof(FrameCounters) + 255) & ~(size_t)255;
 
 // trace.hip: enqueue one frame.  Outputs are device pointers (may be null).
 int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws,

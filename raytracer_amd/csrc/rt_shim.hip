@@ -167,7 +167,7 @@ void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
                      ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
-                     ws.sq_counts, ws.trace_cursors, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1] };
+                     ws.sq_counts, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -180,9 +180,17 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
     const bool wavefront = pipe == 2;
     FrameWorkspace &ws = c->ws;
     // (hipFree of a buffer waits for the device by itself; the frees below are the only way a buffer goes away)
-    if (!ws.counters) {
-        if (hipMalloc((void **)&ws.counters, sizeof(FrameCounters)) != hipSuccess)
-            return fail(RT_E_NOMEM, "hipMalloc(counters) failed");
+    // frame counters + claim cursors: one block, cleared by one memset per frame
+    {
+        const int chunks = (c->n_lights + 31) / 32;
+        const size_t need = COUNTERS_PAD + (wavefront ? sizeof(unsigned int) * wavefront_cursor_words(levels, chunks) : 0);
+        if (need > ws.zero_cap) {
+            if (ws.counters) (void)hipFree(ws.counters);
+            ws.counters = nullptr; ws.trace_cursors = nullptr; ws.zero_cap = 0;
+            if (hipMalloc((void **)&ws.counters, need) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(counters and claim cursors) failed");
+            ws.zero_cap = need;
+            ws.trace_cursors = (unsigned int *)((char *)ws.counters + COUNTERS_PAD);
+        }
     }
     // ray queues are indexed by slot (the frame padded to whole 8x8 tiles, rounded up to whole regions)
     const size_t qslots = wavefront_regions(slots > pixels ? slots : pixels) * 256;
@@ -237,14 +245,6 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_counts, sizeof(unsigned int) * regions * (size_t)(gc ? gc : 1));
             if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("wavefront workspace: ") + hipGetErrorString(e));
             ws.slots_cap = sc; ws.chunks_cap = cc; ws.seg_cap = gc;
-        }
-        const size_t ctr = wavefront_cursor_words(levels, n_chunks);
-        if (ctr > ws.cursors_cap) {
-            if (ws.trace_cursors) (void)hipFree(ws.trace_cursors);
-            ws.trace_cursors = nullptr; ws.cursors_cap = 0;
-            if (hipMalloc((void **)&ws.trace_cursors, sizeof(unsigned int) * ctr) != hipSuccess)
-                return fail(RT_E_NOMEM, "hipMalloc(claim cursors) failed");
-            ws.cursors_cap = ctr;
         }
         const size_t ovf = wavefront_overflow_ints(cus);
         if (ovf > ws.overflow_cap) {

@@ -416,7 +416,15 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     const int n_rows = fp.rows.n_rows;
     const int n_pixels = fp.W * n_rows;
     if (device_num_cus(err) <= 0) return RT_E_DEVICE;
-    RT_HIP_CHECK(hipMemsetAsync(ws.counters, 0, sizeof(FrameCounters), stream), err);
+    const int pipe = scene.accel == 1 ? lbvh_pipeline(fp.pipeline, scene.n_lights) : 1;
+    const bool wavefront = pipe == 2;
+    {
+        // one memset for everything a frame expects to find zero: the counters and, for the staged pipeline, the
+        // claim cursors of all its traversal launches (they sit behind the counters in one allocation)
+        size_t clear = (sizeof(FrameCounters) + 15) & ~(size_t)15;
+        if (wavefront) clear = COUNTERS_PAD + sizeof(unsigned int) * wavefront_cursor_words(fp.max_depth + 1, (scene.n_lights + 31) / 32);
+        RT_HIP_CHECK(hipMemsetAsync(ws.counters, 0, clear, stream), err);
+    }
 
     BounceArgs a;
     a.sc = scene;
@@ -449,8 +457,6 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     int launches = 0;
     const int full_grid = g_num_cus * 8;
     if (int rc = stamp()) return rc;
-    const int pipe = scene.accel == 1 ? lbvh_pipeline(fp.pipeline, scene.n_lights) : 1;
-    const bool wavefront = pipe == 2;
     if (wavefront) {
         std::function<int()> st = stamp;
         if (int rc = wavefront_frame(scene, cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, g_num_cus, st, &launches, err))

@@ -554,8 +554,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         if (err) *err = "LBVH deeper than the traversal stack";
         return RT_E_LIMIT;
     }
-    RT_HIP_CHECK(hipMemsetAsync(ws.trace_cursors, 0, sizeof(unsigned int) * wavefront_cursor_words(fp.max_depth + 1, n_chunks), stream),
-                 err);
+    // (the claim cursors were cleared with the frame counters: trace_frame)
 
     TraceArgs t;
     t.sc = scene; t.cam = cam; t.W = fp.W; t.n_rows = n_rows; t.rows = fp.rows;
