@@ -1,0 +1,91 @@
+"""Two ranks on ONE GPU: each process builds the scene in its own context, constructs the product's
+PartitionedRenderer(world = 2) on cuda:0 and calls render() — the real rt_render_rows_device and
+rt_deinterleave_bands kernels, the real stream ordering, the real band partition — with the slices exchanged
+over a gloo process group (RCCL refuses two ranks on one device, so the collective is the one part that differs
+from the 8-GPU job: the gather is staged through host memory by a shim with torch.distributed's signature).
+Rank 0's frame must equal the frame rendered whole, for a camera that changes between frames."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from common import atrium_spec, rt, to_product
+
+pytestmark = pytest.mark.gpu
+
+W, H, D, BAND = 320, 200, 3, 16
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cams():
+    return [rt.Camera(origin=(0.3 * k - 0.3, -1.5, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4) for k in range(3)]
+
+
+class _HostStagedGather:
+    """all_gather_into_tensor over gloo for device tensors: through host memory, ordered on the current stream."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def all_gather_into_tensor(self, out, inp):
+        torch = self.torch
+        torch.cuda.current_stream().synchronize()           # the slice is complete before it leaves the device
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host_out, inp.cpu())
+        out.copy_(host_out, non_blocking=False)             # enqueued on the current stream, ahead of the de-interleave
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.dist import PartitionedRenderer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        with rt.Context(0) as ctx:
+            to_product(ctx, atrium_spec(detail=0.02))
+            ctx.set_option(rt.OPT_TIMING, 0)
+            pr = PartitionedRenderer(ctx, W, H, D, rank, world, BAND, torch.device("cuda", 0), dist=_HostStagedGather(dist, torch))
+            frames = []
+            for cam in _cams():
+                ctx.set_camera(cam)
+                out = pr.render()
+                torch.cuda.current_stream().synchronize()
+                if rank == 0:
+                    frames.append(out.cpu().numpy().copy())
+            if rank == 0:
+                q.put(frames)
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_on_one_gpu_reassemble_the_frame():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        frames = q.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    with rt.Context(0) as c:
+        to_product(c, atrium_spec(detail=0.02))
+        for cam, got in zip(_cams(), frames):
+            c.set_camera(cam)
+            want = c.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"]
+            assert np.array_equal(got, want)
+    assert not np.array_equal(frames[0], frames[1])
