@@ -21,6 +21,8 @@
 
 #include <float.h>
 
+#include <algorithm>
+
 #include <new>
 
 namespace {
@@ -222,6 +224,18 @@ __global__ void k_split_count(const float4 *__restrict__ tri_mt, int n, const un
     if (i >= n) return;
     const SplitGrid g = split_grid(tri_mt, i, bounds, max_cells);
     counts[i] = (unsigned)(g.n[0] * g.n[1] * g.n[2]);
+}
+
+// Sum of the cell counts in 64 bits (the 32-bit scan that follows must not wrap): wave and block reduce, one atomic per block.
+__global__ __launch_bounds__(256) void k_sum_counts(const unsigned int *__restrict__ counts, int n, unsigned long long *total)
+{
+    __shared__ unsigned long long s_sum[4];
+    unsigned long long v = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += counts[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
 // One thread per cell of every triangle's grid (cell_off = exclusive scan of the counts, n_cells their sum): the box of
@@ -1065,6 +1079,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
         if (err) *err = "split cells per axis must be 1..32";
         return RT_E_INVALID;
     }
+    const int split_requested = split_cells;     // what the caller asked for (the grid below may be made coarser to fit a budget)
     EventPair ev;
     RT_HIP_CHECK(ev.create(), err);
     const hipEvent_t ev0 = ev.a, ev1 = ev.b;
@@ -1088,15 +1103,30 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
             if (err) *err = "lbvh_build allocation: reference scan";
             return RT_E_NOMEM;
         }
-        hipLaunchKernelGGL(k_split_count, dim3(GT), dim3(256), 0, stream, tri_mt, n_tris, bounds.p, split_cells, counts.p);
-        scan_exclusive<unsigned int>(counts.p, n_tris, total.p, scan_tmp.p, stream);
-        unsigned int n_cells = 0;
-        RT_HIP_CHECK(hipMemcpyAsync(&n_cells, total.p, sizeof n_cells, hipMemcpyDeviceToHost, stream), err);
-        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
-        if (n_cells < (unsigned)n_tris || n_cells >= (1u << 30)) {
-            if (err) *err = "triangle split grid out of range";
-            return n_cells < (unsigned)n_tris ? RT_E_DEVICE : RT_E_LIMIT;
+        // A scene made of nothing but large triangles would ask for up to 1024 cells each: the grid is halved until
+        // the cells fit a budget of 4 per triangle (plus 4 M), which also keeps every 32-bit count below 2^30.
+        DevBuf<unsigned long long> total64;
+        if (total64.alloc(1) != hipSuccess) {
+            if (err) *err = "lbvh_build allocation: reference total";
+            return RT_E_NOMEM;
         }
+        const unsigned long long budget = std::min<unsigned long long>((unsigned long long)n_tris * 4ull + (4ull << 20), (1ull << 30) - 1);
+        unsigned long long cells64 = 0;
+        for (;;) {
+            RT_HIP_CHECK(hipMemsetAsync(total64.p, 0, sizeof(unsigned long long), stream), err);
+            hipLaunchKernelGGL(k_split_count, dim3(GT), dim3(256), 0, stream, tri_mt, n_tris, bounds.p, split_cells, counts.p);
+            hipLaunchKernelGGL(k_sum_counts, dim3(GT < 1024 ? GT : 1024), dim3(256), 0, stream, (const unsigned int *)counts.p, n_tris, total64.p);
+            RT_HIP_CHECK(hipMemcpyAsync(&cells64, total64.p, sizeof cells64, hipMemcpyDeviceToHost, stream), err);
+            RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+            if (cells64 <= budget || split_cells <= 1) break;
+            split_cells = split_cells / 2;
+        }
+        if (cells64 < (unsigned long long)n_tris || cells64 > budget) {
+            if (err) *err = "triangle split grid out of range";
+            return cells64 < (unsigned long long)n_tris ? RT_E_DEVICE : RT_E_LIMIT;
+        }
+        const unsigned int n_cells = (unsigned int)cells64;
+        if (n_cells > (unsigned)n_tris) scan_exclusive<unsigned int>(counts.p, n_tris, total.p, scan_tmp.p, stream);
         if (n_cells > (unsigned)n_tris) {            // some triangle is cut
             DevBuf<unsigned int> scan_tmp2;
             if (cell_tri.alloc(n_cells) != hipSuccess || flags.alloc(n_cells) != hipSuccess || cell_lo.alloc(n_cells) != hipSuccess ||
@@ -1291,7 +1321,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     out->n_nodes = n - 1;
     out->n_refs = n;
-    out->split = split_cells;
+    out->split = split_requested;
     out->depth = live_depth;
     out->wide_depth = wide_depth;
     out->leaf_max = leaf_max;

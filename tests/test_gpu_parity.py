@@ -993,3 +993,38 @@ def test_supplied_obj_workload_renders_like_the_oracle(tmp_path):
     assert_parity(compare(g, r))
     assert rays(st) == orays(r)
     assert (g["hit_id"] >= 0).mean() > 0.5
+
+
+def test_a_scene_of_nothing_but_large_triangles_keeps_its_reference_count_in_budget():
+    """Every triangle here is long against the scene, so an uncapped grid would ask for hundreds of cells each; the
+    builder coarsens the grid until the cells fit its budget (4 per triangle + 4 M), and the frame still equals the
+    uncut hierarchy's and the oracle's."""
+    n = 12000
+    r = np.random.default_rng(4242).random((n, 3, 3))
+    tri = np.empty((n, 3, 3), np.float64)
+    tri[:, 0] = r[:, 0] * [10.0, 6.0, 8.0] + [-5.0, -4.0, -1.0]
+    tri[:, 1] = tri[:, 0] + (r[:, 1] - 0.5) * [16.0, 10.0, 14.0]          # long edges in every direction
+    tri[:, 2] = tri[:, 0] + (r[:, 2] - 0.5) * [0.6, 0.6, 0.6]
+    from common import SceneSpec
+    spec = SceneSpec([sphere_((2.0, 5.0, 1.0), 0.1, True, (0.7, 0.7, 0.9))], tri.reshape(-1, 3).astype(np.float32),
+                     np.arange(3 * n, dtype=np.int32), (0.3, 1.0, 1.0, (0.8, 0.8, 0.8)))
+    cam = rt.Camera(pitch=0.1)
+    W, H, D = 80, 60, 2
+    frames = {}
+    for split in (1, 0):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+            ctx.set_option(rt.OPT_SPLIT, split)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            frames[split] = (ctx.render_frame(W, H, max_depth=D), ctx.stats())
+            again = ctx.render_frame(W, H, max_depth=D)           # no rebuild between frames: same tree, same bytes
+            assert ctx.stats()["bvh_nodes"] == frames[split][1]["bvh_nodes"]
+            assert np.array_equal(again["rgb8"], frames[split][0]["rgb8"])
+    assert frames[1][1]["bvh_nodes"] == n - 1
+    assert n - 1 < frames[0][1]["bvh_nodes"] <= 4 * n + (4 << 20)
+    for k in ("rgb8", "hit_id", "rgb32"):
+        assert np.array_equal(frames[0][0][k].view(np.uint8), frames[1][0][k].view(np.uint8)), k
+    o = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam), threads=8)
+    assert_parity(compare(frames[0][0], o))
+    assert rays(frames[0][1]) == orays(o)
