@@ -46,15 +46,18 @@ def _lib_deps():
     return srcs, srcs + hdrs + [os.path.join(ROOT, "include", "rt_shim.h"), __file__]
 
 
+TRAVERSAL_SOURCES = ["wavefront.hip", "rt_traverse.h", "rt_device.h", "rt_internal.h", "lbvh.hip"]
+
+
 def source_hash():
-    """sha256 over the device sources the library is built from: the key that ties a committed counter
-    measurement (profiles/hbm_traffic.json) to the kernels it was measured on."""
+    """sha256 over the sources that decide what the traversal kernel fetches (the kernel itself, its device headers and
+    the hierarchy builder): the key that ties a committed counter measurement (profiles/hbm_traffic.json) to the
+    kernels it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(_lib_deps()[1]):
-        if path.endswith((".hip", ".h")):
-            h.update(os.path.basename(path).encode())
-            h.update(open(path, "rb").read())
+    for name in TRAVERSAL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]
 
 
