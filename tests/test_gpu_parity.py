@@ -1028,3 +1028,53 @@ def test_a_scene_of_nothing_but_large_triangles_keeps_its_reference_count_in_bud
     o = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam), threads=8)
     assert_parity(compare(frames[0][0], o))
     assert rays(frames[0][1]) == orays(o)
+
+
+def test_maximum_depth_and_maximum_analytic_count():
+    """The stated maxima: RT_MAX_DEPTH = 64 bounce levels (a hall of mirrors: two facing reflective planes, a mirror
+    mesh between them, so chains really run 64 deep) through both pipelines, and RT_MAX_ANALYTIC = 1024 analytic
+    primitives (512 of them lights: 16 chunks of 32) in one scene; one more of either is refused."""
+    from common import SceneSpec, plane, sphere
+    mirror = (0.9, 0.3, 1.0, (0.9, 0.9, 1.0))
+    a = [plane((0.0, 0.0, 1.0), -6.0, mirror), plane((0.0, 0.0, -1.0), -9.0, mirror), plane((0.0, 1.0, 0.0), -4.0),
+         sphere((1.0, 3.0, 2.0), 0.1, (0.0, 1.0, 1.0, (0.9, 0.9, 0.8)), True)]
+    small = soup_spec(n_tris=60, seed=17)
+    spec = SceneSpec(a, small.verts, small.indices, mats=[(0.8, 0.4, 1.0, (1.0, 1.0, 1.0)), (0.0, 1.0, 1.0, (0.8, 0.2, 0.2))],
+                     tri_material=(np.arange(60) % 2).astype(np.int32))
+    cam = rt.Camera(pitch=0.1)
+    W, H, D = 80, 60, rt.RT_MAX_DEPTH
+    r = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam), threads=8)
+    assert r["counts"]["reflect"] > 10 * W * H          # the chains are deep
+    for accel, pipeline in ((rt.ACCEL_LINEAR, 0), (rt.ACCEL_LBVH, rt.PIPELINE_FUSED), (rt.ACCEL_LBVH, rt.PIPELINE_WAVEFRONT)):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, accel)
+            ctx.set_option(rt.OPT_PIPELINE, pipeline)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            g = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            assert_parity(compare(g, r))
+            assert rays(st) == orays(r)
+            with pytest.raises(rt.RtError) as e:
+                ctx.render_frame(W, H, max_depth=D + 1)
+            assert e.value.code == -1
+    # 1024 analytic primitives: 512 small light spheres on a ring, 511 plain spheres, one floor
+    prims = [plane((0.0, 1.0, 0.0), -4.0)]
+    for k in range(512):
+        t = 2.0 * np.pi * k / 512
+        prims.append(sphere((6.0 * np.cos(t), 4.0 + 0.5 * np.sin(5 * t), 4.0 + 6.0 * np.sin(t)), 0.03, (0.0, 1.0, 1.0, (0.004, 0.004, 0.004)), True))
+    for k in range(511):
+        t = 2.0 * np.pi * k / 511
+        prims.append(sphere((3.0 * np.cos(t), -3.5 + 0.002 * k, 4.0 + 3.0 * np.sin(t)), 0.12, (0.2, 1.0, 1.0, (0.6, 0.7, 0.9))))
+    assert len(prims) == rt.RT_MAX_ANALYTIC
+    big = SceneSpec(prims, small.verts, small.indices, (0.0, 1.0, 1.0, (1.0, 1.0, 1.0)))
+    W2, H2 = 48, 36
+    r2 = to_oracle(big).render(W2, H2, max_depth=1, cam=ocam(cam), threads=8)
+    for accel in (rt.ACCEL_LINEAR, rt.ACCEL_LBVH):
+        g = render(big, W2, H2, 1, cam, accel)
+        assert_parity(compare(g, r2))
+        assert rays(g["stats"]) == orays(r2)
+    with rt.Context(0) as ctx:
+        with pytest.raises(rt.RtError) as e:
+            ctx.set_analytic([rt.Sphere((0.0, 0.0, 0.0), 1.0)] * (rt.RT_MAX_ANALYTIC + 1))
+        assert e.value.code == -5
