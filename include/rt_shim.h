@@ -95,6 +95,9 @@ typedef struct {
     int32_t accel;         /* 0 = linear scan over triangles, 1 = LBVH */
     float ms_build;        /* device time of the last LBVH build */
     float ms_traverse;     /* LBVH scenes: sum of the traversal kernels alone (part of ms_trace) */
+    float bvh_sah_cost;    /* surface-area-heuristic cost of the hierarchy as built: (sum of inner-node areas + sum of leaf areas x
+                              triangles in the leaf) / root area; lower is better, refits do not update it */
+    int32_t bvh_refs;      /* triangle references under the hierarchy (> n_triangles when large triangles were cut, RT_OPT_SPLIT) */
 } rt_stats;
 
 enum {

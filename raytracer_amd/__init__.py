@@ -80,7 +80,8 @@ class Stats(C.Structure):
                 ("ms_frame", C.c_float), ("ms_trace", C.c_float), ("ms_resolve", C.c_float),
                 ("n_launches", C.c_int32), ("n_analytic", C.c_int32), ("n_triangles", C.c_int32),
                 ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("bvh_leaf_max", C.c_int32),
-                ("accel", C.c_int32), ("ms_build", C.c_float), ("ms_traverse", C.c_float)]
+                ("accel", C.c_int32), ("ms_build", C.c_float), ("ms_traverse", C.c_float),
+                ("bvh_sah_cost", C.c_float), ("bvh_refs", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -22,6 +22,7 @@
 #include <float.h>
 
 #include <algorithm>
+#include <vector>
 
 #include <new>
 
@@ -685,6 +686,45 @@ __global__ void k_live_level(const int2 *__restrict__ children, const int *__res
     live[i] = 1 + (c.x < n - 1 ? live[c.x] : 0) + (c.y < n - 1 ? live[c.y] : 0);
 }
 
+// Surface-area-heuristic cost of the collapsed binary tree, the usual measure of a hierarchy's quality:
+//   (sum over traversed inner nodes of area(node) + sum over leaves of area(leaf) * triangles in it) / area(root).
+// One thread per inner node adds its own term and the terms of the leaves below it; block reduce, one atomic per block.
+__global__ __launch_bounds__(256) void k_sah_cost(const int2 *__restrict__ children, const int2 *__restrict__ range, int n, int leaf_max,
+                                                  const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi, double *cost)
+{
+    __shared__ double s_sum[4];
+    auto area = [&](int id) -> double {
+        const float4 l = box_lo[id], h = box_hi[id];
+        const double dx = (double)h.x - l.x, dy = (double)h.y - l.y, dz = (double)h.z - l.z;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    };
+    double v = 0.0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n - 1) {
+        const int2 r = range[i];
+        if (i == 0 || r.y - r.x + 1 > leaf_max) {           // a node the traversal visits
+            v = area(i);
+            const int2 c = children[i];
+            const int cc[2] = { c.x, c.y };
+            for (int k = 0; k < 2; k++) {
+                if (cc[k] >= n - 1) v += area(cc[k]);                                   // a single reference
+                else {
+                    const int2 rc = range[cc[k]];
+                    const int cnt = rc.y - rc.x + 1;
+                    if (cnt <= leaf_max) v += area(cc[k]) * (double)cnt;                // a collapsed subtree
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (t != 0.0) atomicAdd(cost, t);
+    }
+}
+
 __global__ void k_pre_level(const int2 *__restrict__ children, const int *__restrict__ depth, int n, int level,
                             const int *__restrict__ live, int *pre)
 {
@@ -1064,6 +1104,100 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, int split
 
 namespace {
 
+// ---- builder 3: a top-down binned SAH tree built on the HOST over the reference boxes (measurement of what tree
+// quality is worth; the default builders run on the device).  Output in the Karras layout: inner nodes 0..n-2 with root
+// 0, leaf k = (n-1)+k, leaves numbered left to right so that every subtree covers a contiguous range.
+struct HostSah {
+    const float4 *lo, *hi;
+    std::vector<unsigned int> order;        // leaf k holds reference order[k]
+    std::vector<int2> children, range;
+    std::vector<int> parent;
+    int next_inner = 0;
+    static constexpr int BINS = 32;
+
+    static double half_area(const float l[3], const float h[3])
+    {
+        const double dx = (double)h[0] - l[0], dy = (double)h[1] - l[1], dz = (double)h[2] - l[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    // builds the subtree over order[first..last]; returns its node id
+    int build(int first, int last, int par)
+    {
+        const int n = (int)order.size();
+        if (first == last) {
+            parent[(n - 1) + first] = par;
+            return (n - 1) + first;
+        }
+        const int id = next_inner++;
+        parent[id] = par;
+        range[id] = make_int2(first, last);
+        int mid = (first + last + 1) / 2;                    // fallback: the middle
+        if (last - first >= 2) {
+            float clo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, chi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            for (int k = first; k <= last; k++) {
+                const float4 l = lo[order[k]], h = hi[order[k]];
+                const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
+                for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], c[a]); chi[a] = fmaxf(chi[a], c[a]); }
+            }
+            double best = 1e300;
+            int best_axis = -1, best_split = 0;
+            for (int a = 0; a < 3; a++) {
+                const float ext = chi[a] - clo[a];
+                if (!(ext > 0.f)) continue;
+                int cnt[BINS] = { 0 };
+                float bl[BINS][3], bh[BINS][3];
+                for (int b = 0; b < BINS; b++)
+                    for (int q = 0; q < 3; q++) { bl[b][q] = FLT_MAX; bh[b][q] = -FLT_MAX; }
+                const float scale = (float)BINS / ext;
+                for (int k = first; k <= last; k++) {
+                    const float4 l = lo[order[k]], h = hi[order[k]];
+                    const float c = 0.5f * ((&l.x)[a] + (&h.x)[a]);
+                    int b = (int)((c - clo[a]) * scale);
+                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                    cnt[b]++;
+                    bl[b][0] = fminf(bl[b][0], l.x); bl[b][1] = fminf(bl[b][1], l.y); bl[b][2] = fminf(bl[b][2], l.z);
+                    bh[b][0] = fmaxf(bh[b][0], h.x); bh[b][1] = fmaxf(bh[b][1], h.y); bh[b][2] = fmaxf(bh[b][2], h.z);
+                }
+                double right_cost[BINS];
+                {
+                    float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+                    int c = 0;
+                    for (int b = BINS - 1; b > 0; b--) {
+                        for (int q = 0; q < 3; q++) { l[q] = fminf(l[q], bl[b][q]); h[q] = fmaxf(h[q], bh[b][q]); }
+                        c += cnt[b];
+                        right_cost[b] = c ? half_area(l, h) * c : 0.0;
+                    }
+                }
+                float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+                int c = 0;
+                for (int b = 0; b + 1 < BINS; b++) {
+                    for (int q = 0; q < 3; q++) { l[q] = fminf(l[q], bl[b][q]); h[q] = fmaxf(h[q], bh[b][q]); }
+                    c += cnt[b];
+                    if (c == 0 || c == last - first + 1) continue;
+                    const double cost = half_area(l, h) * c + right_cost[b + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_split = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                const float scale = (float)BINS / (chi[a] - clo[a]);
+                auto bin_of = [&](unsigned int r) {
+                    const float4 l = lo[r], h = hi[r];
+                    int b = (int)((0.5f * ((&l.x)[a] + (&h.x)[a]) - clo[a]) * scale);
+                    return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                };
+                unsigned int *f = order.data() + first, *e = order.data() + last + 1;
+                unsigned int *m = std::partition(f, e, [&](unsigned int r) { return bin_of(r) <= best_split; });
+                const int cut = (int)(m - order.data());
+                if (cut > first && cut <= last) mid = cut;
+            }
+        }
+        const int left = build(first, mid - 1, id), right = build(mid, last, id);
+        children[id] = make_int2(left, right);
+        return id;
+    }
+};
+
 int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
                     std::string *err)
 {
@@ -1197,9 +1331,29 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
         return RT_E_NOMEM;
     }
     const int B = 256, G = blocks_for(n, B);
-    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, n, bounds.p, keys[0].p, vals[0].p);
     int cur = 0;
-    for (int pass = 0; pass < 8; pass++) {
+    const bool host_sah = builder == 3;
+    if (host_sah) {
+        std::vector<float4> h_lo((size_t)n), h_hi((size_t)n);
+        RT_HIP_CHECK(hipMemcpyAsync(h_lo.data(), ref_lo.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(h_hi.data(), ref_hi.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+        HostSah hs;
+        hs.lo = h_lo.data(); hs.hi = h_hi.data();
+        hs.order.resize((size_t)n);
+        for (int k = 0; k < n; k++) hs.order[(size_t)k] = (unsigned)k;
+        hs.children.assign((size_t)n, make_int2(0, 0)); hs.range.assign((size_t)n, make_int2(0, 0));
+        hs.parent.assign(2 * (size_t)n, -1);
+        hs.build(0, n - 1, -1);
+        RT_HIP_CHECK(hipMemcpyAsync(vals[0].p, hs.order.data(), sizeof(unsigned int) * (size_t)n, hipMemcpyHostToDevice, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(children.p, hs.children.data(), sizeof(int2) * (size_t)n, hipMemcpyHostToDevice, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(range.p, hs.range.data(), sizeof(int2) * (size_t)n, hipMemcpyHostToDevice, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(parent.p, hs.parent.data(), sizeof(int) * 2 * (size_t)n, hipMemcpyHostToDevice, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);       // the host vectors go out of scope
+    } else {
+        hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, n, bounds.p, keys[0].p, vals[0].p);
+    }
+    for (int pass = 0; pass < 8 && !host_sah; pass++) {
         int shift = pass * 8;
         hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, n, shift, hist.p, n_tiles);
         scan_exclusive<unsigned int>(hist.p, 256 * n_tiles, (unsigned int *)nullptr, scan_u32.p, stream);
@@ -1210,14 +1364,15 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
-    const bool ploc = builder != 1;
+    const bool ploc = builder != 1 && !host_sah;
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
     DevBuf<unsigned long long> flags, totals;
     hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
     if (!ploc) {
-        hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
-                           parent.p);
+        if (!host_sah)
+            hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
+                               parent.p);
         hipLaunchKernelGGL(k_node_depth, dim3(min(blocks_for(n - 1, 256), 2048)), dim3(256), 0, stream, parent.p, n - 1, depth.p, scalars.p);
         RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipStreamSynchronize(stream), err);
@@ -1281,6 +1436,11 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
                        leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes,
                        grid.p, scalars.p + 1);
+    DevBuf<double> sah;
+    if (sah.alloc(1) == hipSuccess) {
+        RT_HIP_CHECK(hipMemsetAsync(sah.p, 0, sizeof(double), stream), err);
+        hipLaunchKernelGGL(k_sah_cost, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, n, leaf_max, box_lo.p, box_hi.p, sah.p);
+    }
     DevBuf<int> wide, pre4, root, slot;
     DevBuf<int4> wkids;
     if (wide.alloc(n) != hipSuccess || pre4.alloc(n) != hipSuccess || root.alloc(n) != hipSuccess || slot.alloc(n) != hipSuccess ||
@@ -1316,7 +1476,19 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     RT_HIP_CHECK(hipMemcpyAsync(&live_depth, scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream), err);
     RT_HIP_CHECK(hipMemcpyAsync(&wide_depth, scalars.p + 2, sizeof(int), hipMemcpyDeviceToHost, stream), err);
     RT_HIP_CHECK(hipMemcpyAsync(&out->grid, grid.p, sizeof(QuantGrid), hipMemcpyDeviceToHost, stream), err);
+    double sah_sum = 0.0;
+    float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = root_lo;
+    if (sah.p) {
+        RT_HIP_CHECK(hipMemcpyAsync(&sah_sum, sah.p, sizeof(double), hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(&root_lo, box_lo.p, sizeof(float4), hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipMemcpyAsync(&root_hi, box_hi.p, sizeof(float4), hipMemcpyDeviceToHost, stream), err);
+    }
     RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+    {
+        const double dx = (double)root_hi.x - root_lo.x, dy = (double)root_hi.y - root_lo.y, dz = (double)root_hi.z - root_lo.z;
+        const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
+        out->sah_cost = a > 0.0 ? (float)(sah_sum / a) : 0.f;
+    }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     out->n_nodes = n - 1;

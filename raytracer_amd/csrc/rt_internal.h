@@ -110,6 +110,7 @@ struct LbvhResult {
     int n_nodes = 0, depth = 0, wide_depth = 0, leaf_max = 0, builder = 0;
     int n_refs = 0, split = 0;     // triangle references under the hierarchy; cells per axis a triangle was allowed to be cut into
     float ms_build = 0.f;
+    float sah_cost = 0.f;          // surface-area-heuristic cost of the collapsed binary tree (node cost 1, triangle cost 1)
 };
 
 // lbvh.hip: builds the LBVH over tri_mt (device) on `stream`.  Returns RT_* code.

@@ -532,7 +532,7 @@ int rt_set_option(rt_ctx *c, int option, int value)
         return RT_OK;
     case RT_OPT_TIMING: c->opt_timing = value ? 1 : 0; return RT_OK;
     case RT_OPT_BUILDER:
-        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_BUILDER takes 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(RT_E_INVALID, "RT_OPT_BUILDER takes 0..3");
         c->opt_builder = value;
         return RT_OK;
     case RT_OPT_SPLIT:
@@ -1020,6 +1020,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->bvh_depth = c->bvh.depth;
     out->bvh_leaf_max = c->bvh.leaf_max;
     out->ms_build = c->bvh.ms_build;
+    out->bvh_sah_cost = c->bvh.sah_cost;
+    out->bvh_refs = c->bvh.n_refs;
     if (!c->frame_valid) return RT_OK;
     FrameCounters fc;
     if (hipMemcpy(&fc, c->last_counters ? c->last_counters : c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)

@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(rt.Analytic) == 8 + 24 + 12 + 4
     assert ctypes.sizeof(rt.Camera) == 28
     assert ctypes.sizeof(rt.RowSet) == 16
-    assert ctypes.sizeof(rt.Stats) == 96   # 6 x u64 + 3 x f32 + 7 x i32 + 2 x f32
+    assert ctypes.sizeof(rt.Stats) == 104  # 6 x u64 + 3 x f32 + 7 x i32 + 3 x f32 + 1 x i32
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():
