@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true", help="issue every launch of every frame instead of replaying a hipGraph")
-    ap.add_argument("--builder", type=int, default=0, help="0 auto, 1 Karras LBVH, 2 PLOC")
+    ap.add_argument("--builder", type=int, default=0, help="0 auto (= 3), 1 Karras LBVH, 2 PLOC, 3 binned SAH")
     ap.add_argument("--lib", default="", help="another build of librt_amd.so to load (A/B runs of kernel variants)")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto, 1 fused bounce kernel, 2 wavefront stages")
     return ap.parse_args()

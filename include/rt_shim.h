@@ -106,7 +106,8 @@ enum {
     RT_OPT_LEAF_MAX = 3,     /* triangles per LBVH leaf, 1..8 (takes effect at the next rt_set_*triangles) */
     RT_OPT_TIMING = 4,       /* 1 (default): record per-kernel device events for rt_get_stats */
     RT_OPT_PIPELINE = 5,     /* LBVH scenes: 0 auto (= 2), 1 one fused kernel per bounce level, 2 separate traversal / ray-generation / shading stages */
-    RT_OPT_BUILDER = 6,      /* hierarchy over the Morton-sorted triangles: 0 auto (= 2), 1 Karras LBVH, 2 PLOC agglomeration */
+    RT_OPT_BUILDER = 6,      /* how the hierarchy is built (always on the GPU): 0 auto (= 3), 1 Karras LBVH over Morton codes, 2 PLOC
+                                agglomeration over the Morton order, 3 top-down binned surface-area-heuristic sweep */
     RT_OPT_SPLIT = 8,        /* hierarchy build: the most cells per axis a large triangle is cut into (each cell it reaches becomes one
                                 reference with a clipped box; hits are unchanged): 0 auto (= 32), 1 never cut, up to 32; takes effect at
                                 the next build */

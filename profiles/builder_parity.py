@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "sponza"
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 wl = workloads.by_name(name, W=W, H=H)
 ref = None
-for builder in (rt.BUILDER_PLOC, rt.BUILDER_LBVH, 3):
+for builder in (rt.BUILDER_PLOC, rt.BUILDER_LBVH, rt.BUILDER_SAH):
     with rt.Context(0) as ctx:
         ctx.set_option(rt.OPT_BUILDER, builder)
         ctx.set_option(rt.OPT_TIMING, 1)

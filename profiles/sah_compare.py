@@ -66,7 +66,7 @@ def host_sah_cost(lo, hi, leaf_max=2, bins=32):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "sponza"
     wl = workloads.by_name(name, W=64, H=36)
-    for builder, label in ((rt.BUILDER_PLOC, "PLOC (default)"), (rt.BUILDER_LBVH, "Karras LBVH")):
+    for builder, label in ((rt.BUILDER_SAH, "binned SAH (default)"), (rt.BUILDER_PLOC, "PLOC"), (rt.BUILDER_LBVH, "Karras LBVH")):
         for split in (1, 0):
             with rt.Context(0) as ctx:
                 ctx.set_option(rt.OPT_BUILDER, builder)

@@ -22,7 +22,6 @@
 #include <float.h>
 
 #include <algorithm>
-#include <vector>
 
 #include <new>
 
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(256) void k_node_depth(const int *__restrict__ pare
     int deepest = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_internal; i += gridDim.x * blockDim.x) {
         int d = 0;
-        for (int p = parent[i]; p >= 0; p = parent[p]) d++;
+        for (int p = parent[i]; p >= 0 && d <= n_internal; p = parent[p]) d++;     // the bound ends the walk on a malformed tree
         depth[i] = d;
         deepest = max(deepest, d);
     }
@@ -993,6 +992,33 @@ __global__ void k_init_bounds(unsigned int *bounds)
     else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
 }
 
+// Is this a binary tree over leaves 0..n-1 in order?  Every inner node's children must name it as their parent and
+// split its leaf range without gap or overlap, the root must span everything, and the order array must hold every
+// reference once.  bad[0] counts violations.
+__global__ void k_tree_check(const int2 *__restrict__ children, const int2 *__restrict__ range, const int *__restrict__ parent,
+                             const unsigned int *__restrict__ order, int n, int *seen, int *bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned int r = order[i];
+        if (r >= (unsigned)n || atomicAdd(&seen[r], 1) != 0) atomicAdd(bad, 1);
+    }
+    if (i >= n - 1) return;
+    const int2 c = children[i], rg = range[i];
+    int fails = 0;
+    if (i == 0 && (parent[0] != -1 || rg.x != 0 || rg.y != n - 1)) fails++;
+    if (rg.x < 0 || rg.y >= n || rg.x >= rg.y) fails++;
+    int2 sub[2];
+    const int kid[2] = { c.x, c.y };
+    for (int k = 0; k < 2; k++) {
+        if (kid[k] <= 0 || kid[k] > 2 * n - 2 || kid[k] == i) { fails++; sub[k] = make_int2(0, 0); continue; }
+        if (parent[kid[k]] != i) fails++;
+        sub[k] = kid[k] >= n - 1 ? make_int2(kid[k] - (n - 1), kid[k] - (n - 1)) : range[kid[k]];
+    }
+    if (sub[0].x != rg.x || sub[0].y + 1 != sub[1].x || sub[1].y != rg.y) fails++;
+    if (fails) atomicAdd(bad, fails);
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -1104,99 +1130,398 @@ int lbvh_build(const float4 *tri_mt, int n, int leaf_max, int builder, int split
 
 namespace {
 
-// ---- builder 3: a top-down binned SAH tree built on the HOST over the reference boxes (measurement of what tree
-// quality is worth; the default builders run on the device).  Output in the Karras layout: inner nodes 0..n-2 with root
-// 0, leaf k = (n-1)+k, leaves numbered left to right so that every subtree covers a contiguous range.
-struct HostSah {
-    const float4 *lo, *hi;
-    std::vector<unsigned int> order;        // leaf k holds reference order[k]
-    std::vector<int2> children, range;
-    std::vector<int> parent;
-    int next_inner = 0;
-    static constexpr int BINS = 32;
+// ------------------------------------------------------------------ top-down binned SAH (builder 3)
+// The tree a surface-area-heuristic sweep gives, built on the device.  Every open node owns a contiguous
+// range ("segment") of one order array.  A segment longer than SAH_SMALL references is split by the whole grid, one
+// tree level per round: every reference drops its box into one of SAH_BINS bins per axis (atomics, collected in LDS
+// first when a block lies inside one segment), one thread per segment sweeps the 3 x (SAH_BINS-1) planes for the
+// cheapest cut, a scan of the "goes left" flags places every reference (a stable partition), and the children's
+// centroid bounds are gathered on the way.  A segment of at most SAH_SMALL references is finished by ONE wave, down to
+// single references, out of LDS.  Node ids: a node that cuts its range after position g ("gamma") is inner node g --
+// every gap between neighbouring leaves is cut by exactly one node, so the ids are unique in 0..n-2 -- except that the
+// root is node 0 and the node cutting after position 0 takes the root's gamma instead.  Leaf k is (n-1)+k.
+constexpr int SAH_BINS = 32;
+constexpr int SAH_SMALL = 64;
+constexpr int SAH_SMALL_BINS = 16;
+constexpr int SAH_DEPTH_CAP = 60;      // a node at depth d over s references is cut in the middle once d + ceil(log2 s) reaches this
 
-    static double half_area(const float l[3], const float h[3])
-    {
-        const double dx = (double)h[0] - l[0], dy = (double)h[1] - l[1], dz = (double)h[2] - l[2];
-        return dx * dy + dy * dz + dz * dx;
+struct SahSeg { int first, last, parent, side, depth; };
+struct SahBin { unsigned int count, lo[3], hi[3]; };
+struct SahCut { int axis, bin, n_left, slot_left, slot_right; };     // axis < 0: cut in the middle of the range
+
+__device__ __forceinline__ int sah_bin_of(float c, float lo, float hi, int nb)
+{
+    const float ext = hi - lo;
+    if (!(ext > 0.f)) return 0;
+    const int b = (int)((c - lo) * ((float)nb / ext));
+    return b < 0 ? 0 : (b >= nb ? nb - 1 : b);
+}
+
+__device__ __forceinline__ int ceil_log2(int v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
+
+__device__ __forceinline__ float half_area3(const float *l, const float *h)
+{
+    const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// ord[p] = p, every position in segment 0 (or in none when the whole input is one small segment); centroid bounds of
+// the root: per-wave reduction, six atomics per wave.
+__global__ __launch_bounds__(256) void k_sah_init(const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi, int n, int root_slot,
+                                                  unsigned int *ord, int *seg_of, unsigned int *cb)
+{
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        ord[p] = (unsigned)p;
+        seg_of[p] = root_slot;
+        const float4 l = ref_lo[p], h = ref_hi[p];
+        const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], c[k]); hi[k] = fmaxf(hi[k], c[k]); }
     }
-    // builds the subtree over order[first..last]; returns its node id
-    int build(int first, int last, int par)
-    {
-        const int n = (int)order.size();
-        if (first == last) {
-            parent[(n - 1) + first] = par;
-            return (n - 1) + first;
+    for (int k = 0; k < 3; k++)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
-        const int id = next_inner++;
-        parent[id] = par;
-        range[id] = make_int2(first, last);
-        int mid = (first + last + 1) / 2;                    // fallback: the middle
-        if (last - first >= 2) {
-            float clo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, chi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-            for (int k = first; k <= last; k++) {
-                const float4 l = lo[order[k]], h = hi[order[k]];
-                const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
-                for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], c[a]); chi[a] = fmaxf(chi[a], c[a]); }
-            }
-            double best = 1e300;
-            int best_axis = -1, best_split = 0;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&cb[k], float_to_ordered(lo[k]));
+            atomicMax(&cb[3 + k], float_to_ordered(hi[k]));
+        }
+}
+
+__global__ void k_sah_clear(SahBin *bins, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    SahBin b;
+    b.count = 0;
+    for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
+    bins[i] = b;
+}
+
+__device__ __forceinline__ void sah_bin_add(SahBin *b, const float4 l, const float4 h)
+{
+    atomicAdd(&b->count, 1u);
+    atomicMin(&b->lo[0], float_to_ordered(l.x)); atomicMin(&b->lo[1], float_to_ordered(l.y)); atomicMin(&b->lo[2], float_to_ordered(l.z));
+    atomicMax(&b->hi[0], float_to_ordered(h.x)); atomicMax(&b->hi[1], float_to_ordered(h.y)); atomicMax(&b->hi[2], float_to_ordered(h.z));
+}
+
+// Segments are contiguous, so a block whose first and last position name the same segment lies inside it.
+__global__ __launch_bounds__(256) void k_sah_bin(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n,
+                                                 const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi,
+                                                 const unsigned int *__restrict__ cb, int n_act, SahBin *bins)
+{
+    __shared__ SahBin s_bin[3 * SAH_BINS];
+    const int p0 = blockIdx.x * 256, p1 = min(p0 + 255, n - 1);
+    const int s0 = seg_of[p0];
+    const bool same = s0 >= 0 && s0 == seg_of[p1];
+    if (same) {
+        if (threadIdx.x < 3 * SAH_BINS) {
+            SahBin b;
+            b.count = 0;
+            for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
+            s_bin[threadIdx.x] = b;
+        }
+        __syncthreads();
+    }
+    const int p = p0 + threadIdx.x;
+    if (p < n) {
+        const int s = seg_of[p];
+        if (s >= 0 && s < n_act) {
+            const unsigned int r = ord[p];
+            const float4 l = ref_lo[r], h = ref_hi[r];
+            const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
             for (int a = 0; a < 3; a++) {
-                const float ext = chi[a] - clo[a];
-                if (!(ext > 0.f)) continue;
-                int cnt[BINS] = { 0 };
-                float bl[BINS][3], bh[BINS][3];
-                for (int b = 0; b < BINS; b++)
-                    for (int q = 0; q < 3; q++) { bl[b][q] = FLT_MAX; bh[b][q] = -FLT_MAX; }
-                const float scale = (float)BINS / ext;
-                for (int k = first; k <= last; k++) {
-                    const float4 l = lo[order[k]], h = hi[order[k]];
-                    const float c = 0.5f * ((&l.x)[a] + (&h.x)[a]);
-                    int b = (int)((c - clo[a]) * scale);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    cnt[b]++;
-                    bl[b][0] = fminf(bl[b][0], l.x); bl[b][1] = fminf(bl[b][1], l.y); bl[b][2] = fminf(bl[b][2], l.z);
-                    bh[b][0] = fmaxf(bh[b][0], h.x); bh[b][1] = fmaxf(bh[b][1], h.y); bh[b][2] = fmaxf(bh[b][2], h.z);
-                }
-                double right_cost[BINS];
-                {
-                    float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-                    int c = 0;
-                    for (int b = BINS - 1; b > 0; b--) {
-                        for (int q = 0; q < 3; q++) { l[q] = fminf(l[q], bl[b][q]); h[q] = fmaxf(h[q], bh[b][q]); }
-                        c += cnt[b];
-                        right_cost[b] = c ? half_area(l, h) * c : 0.0;
-                    }
-                }
-                float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-                int c = 0;
-                for (int b = 0; b + 1 < BINS; b++) {
-                    for (int q = 0; q < 3; q++) { l[q] = fminf(l[q], bl[b][q]); h[q] = fmaxf(h[q], bh[b][q]); }
-                    c += cnt[b];
-                    if (c == 0 || c == last - first + 1) continue;
-                    const double cost = half_area(l, h) * c + right_cost[b + 1];
-                    if (cost < best) { best = cost; best_axis = a; best_split = b; }
-                }
-            }
-            if (best_axis >= 0) {
-                const int a = best_axis;
-                const float scale = (float)BINS / (chi[a] - clo[a]);
-                auto bin_of = [&](unsigned int r) {
-                    const float4 l = lo[r], h = hi[r];
-                    int b = (int)((0.5f * ((&l.x)[a] + (&h.x)[a]) - clo[a]) * scale);
-                    return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                };
-                unsigned int *f = order.data() + first, *e = order.data() + last + 1;
-                unsigned int *m = std::partition(f, e, [&](unsigned int r) { return bin_of(r) <= best_split; });
-                const int cut = (int)(m - order.data());
-                if (cut > first && cut <= last) mid = cut;
+                const int b = sah_bin_of(c[a], ordered_to_float(cb[6 * s + a]), ordered_to_float(cb[6 * s + 3 + a]), SAH_BINS);
+                sah_bin_add(same ? &s_bin[a * SAH_BINS + b] : &bins[((size_t)s * 3 + a) * SAH_BINS + b], l, h);
             }
         }
-        const int left = build(first, mid - 1, id), right = build(mid, last, id);
-        children[id] = make_int2(left, right);
-        return id;
     }
-};
+    if (same) {
+        __syncthreads();
+        if (threadIdx.x < 3 * SAH_BINS && s0 < n_act) {
+            const SahBin b = s_bin[threadIdx.x];
+            if (b.count) {
+                SahBin *g = &bins[(size_t)s0 * 3 * SAH_BINS + threadIdx.x];
+                atomicAdd(&g->count, b.count);
+                for (int k = 0; k < 3; k++) { atomicMin(&g->lo[k], b.lo[k]); atomicMax(&g->hi[k], b.hi[k]); }
+            }
+        }
+    }
+}
+
+// The id of the node that cuts after position gamma; the root announces its own gamma through *root_gamma.
+__device__ __forceinline__ int sah_node_id(int parent, int gamma, int *root_gamma)
+{
+    if (parent < 0) { *root_gamma = gamma; return 0; }
+    return gamma == 0 ? *root_gamma : gamma;
+}
+
+// Links node `id` under its parent, records its range, and sends its two children on: a single reference becomes a
+// leaf, a short range goes to the list for the wave builder, a long one into the next round (returns its slot there).
+__device__ int sah_child(int id, int side, int first, int last, int depth, int n, int2 *children, int *parent, SahSeg *small, int *n_small,
+                         SahSeg *next, int *n_next, int next_cap, unsigned int *cb_next)
+{
+    const int size = last - first + 1;
+    if (size == 1) {
+        const int leaf = (n - 1) + first;
+        ((int *)(children + id))[side] = leaf;
+        parent[leaf] = id;
+        return -1;
+    }
+    SahSeg sg;
+    sg.first = first; sg.last = last; sg.parent = id; sg.side = side; sg.depth = depth;
+    if (size <= SAH_SMALL) {
+        small[atomicAdd(n_small, 1)] = sg;
+        return -1;
+    }
+    const int k = atomicAdd(n_next, 1);
+    if (k >= next_cap) return -1;            // cannot happen (disjoint ranges longer than SAH_SMALL); the host checks the count
+    next[k] = sg;
+    for (int a = 0; a < 3; a++) { cb_next[6 * k + a] = 0xffffffffu; cb_next[6 * k + 3 + a] = 0u; }
+    return k;
+}
+
+__global__ void k_sah_split(const SahSeg *__restrict__ act, int n_act, const SahBin *__restrict__ bins, int n, int2 *children, int2 *range,
+                            int *parent, int *scalars /*0 root gamma, 1 segments of the next round, 2 small segments*/, SahSeg *small,
+                            SahSeg *next, int next_cap, unsigned int *cb_next, SahCut *cut)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_act) return;
+    const SahSeg seg = act[s];
+    const int size = seg.last - seg.first + 1;
+    float best = FLT_MAX;
+    int axis = -1, bin = 0, n_left = size / 2;
+    if (seg.depth + ceil_log2(size) < SAH_DEPTH_CAP) {
+        for (int a = 0; a < 3; a++) {
+            const SahBin *B = bins + ((size_t)s * 3 + a) * SAH_BINS;
+            float right_cost[SAH_BINS];
+            {
+                float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+                unsigned int c = 0;
+#pragma unroll
+                for (int b = SAH_BINS - 1; b > 0; b--) {
+                    const SahBin q = B[b];
+                    if (q.count) {
+                        for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], ordered_to_float(q.lo[k])); h[k] = fmaxf(h[k], ordered_to_float(q.hi[k])); }
+                        c += q.count;
+                    }
+                    right_cost[b] = c ? half_area3(l, h) * (float)c : 0.f;
+                }
+            }
+            float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            unsigned int c = 0;
+#pragma unroll
+            for (int b = 0; b + 1 < SAH_BINS; b++) {
+                const SahBin q = B[b];
+                if (q.count) {
+                    for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], ordered_to_float(q.lo[k])); h[k] = fmaxf(h[k], ordered_to_float(q.hi[k])); }
+                    c += q.count;
+                }
+                if (c == 0 || c >= (unsigned)size) continue;
+                const float cost = half_area3(l, h) * (float)c + right_cost[b + 1];
+                if (cost < best) { best = cost; axis = a; bin = b; n_left = (int)c; }
+            }
+        }
+    }
+    const int gamma = seg.first + n_left - 1;
+    const int id = sah_node_id(seg.parent, gamma, scalars);
+    parent[id] = seg.parent;
+    range[id] = make_int2(seg.first, seg.last);
+    if (seg.parent >= 0) ((int *)(children + seg.parent))[seg.side] = id;
+    SahCut c;
+    c.axis = axis; c.bin = bin; c.n_left = n_left;
+    c.slot_left = sah_child(id, 0, seg.first, gamma, seg.depth + 1, n, children, parent, small, scalars + 2, next, scalars + 1, next_cap, cb_next);
+    c.slot_right = sah_child(id, 1, gamma + 1, seg.last, seg.depth + 1, n, children, parent, small, scalars + 2, next, scalars + 1, next_cap, cb_next);
+    cut[s] = c;
+}
+
+__global__ void k_sah_flag(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n, const float4 *__restrict__ ref_lo,
+                           const float4 *__restrict__ ref_hi, const SahSeg *__restrict__ act, int n_act, const unsigned int *__restrict__ cb,
+                           const SahCut *__restrict__ cut, unsigned int *flag, unsigned int *scan)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int s = seg_of[p];
+    unsigned int left = 0;
+    if (s >= 0 && s < n_act) {
+        const SahCut c = cut[s];
+        if (c.axis < 0) {
+            left = p - act[s].first < c.n_left;
+        } else {
+            const unsigned int r = ord[p];
+            const float4 l = ref_lo[r], h = ref_hi[r];
+            const float cen = c.axis == 0 ? 0.5f * (l.x + h.x) : (c.axis == 1 ? 0.5f * (l.y + h.y) : 0.5f * (l.z + h.z));
+            left = sah_bin_of(cen, ordered_to_float(cb[6 * s + c.axis]), ordered_to_float(cb[6 * s + 3 + c.axis]), SAH_BINS) <= c.bin;
+        }
+    }
+    flag[p] = left;
+    scan[p] = left;
+}
+
+// scan = exclusive prefix sums of flag.  The partition is stable: both halves keep their order.
+__global__ __launch_bounds__(256) void k_sah_scatter(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n,
+                                                     const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi,
+                                                     const SahSeg *__restrict__ act, int n_act, const SahCut *__restrict__ cut,
+                                                     const unsigned int *__restrict__ flag, const unsigned int *__restrict__ scan,
+                                                     unsigned int *ord_next, int *seg_next, unsigned int *cb_next)
+{
+    __shared__ unsigned int s_cb[2][6];
+    const int p0 = blockIdx.x * 256, p1 = min(p0 + 255, n - 1);
+    const int s0 = seg_of[p0];
+    const bool same = s0 >= 0 && s0 < n_act && s0 == seg_of[p1];
+    if (same) {
+        if (threadIdx.x < 12) s_cb[threadIdx.x / 6][threadIdx.x % 6] = threadIdx.x % 6 < 3 ? 0xffffffffu : 0u;
+        __syncthreads();
+    }
+    const int p = p0 + threadIdx.x;
+    if (p < n) {
+        const int s = seg_of[p];
+        const unsigned int r = ord[p];
+        if (s < 0 || s >= n_act) {
+            ord_next[p] = r;
+            seg_next[p] = -1;
+        } else {
+            const SahSeg seg = act[s];
+            const SahCut c = cut[s];
+            const int left_rank = (int)(scan[p] - scan[seg.first]);
+            const bool left = flag[p] != 0;
+            const int dest = left ? seg.first + left_rank : seg.first + c.n_left + (p - seg.first - left_rank);
+            const int slot = left ? c.slot_left : c.slot_right;
+            ord_next[dest] = r;
+            seg_next[dest] = slot;
+            if (slot >= 0) {
+                const float4 l = ref_lo[r], h = ref_hi[r];
+                const unsigned int cl[3] = { float_to_ordered(0.5f * (l.x + h.x)), float_to_ordered(0.5f * (l.y + h.y)), float_to_ordered(0.5f * (l.z + h.z)) };
+                unsigned int *dst = same ? s_cb[left ? 0 : 1] : cb_next + 6 * (size_t)slot;
+                for (int a = 0; a < 3; a++) { atomicMin(&dst[a], cl[a]); atomicMax(&dst[3 + a], cl[a]); }
+            }
+        }
+    }
+    if (same) {
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const int side = threadIdx.x / 6, k = threadIdx.x % 6;
+            const SahCut c = cut[s0];
+            const int slot = side == 0 ? c.slot_left : c.slot_right;
+            const unsigned int v = s_cb[side][k];
+            if (slot >= 0 && v != (k < 3 ? 0xffffffffu : 0u)) {
+                if (k < 3) atomicMin(&cb_next[6 * (size_t)slot + k], v);
+                else atomicMax(&cb_next[6 * (size_t)slot + k], v);
+            }
+        }
+    }
+}
+
+// One wave finishes one short segment.  Position = lane; the boxes live in LDS and move with the partition.  Lane j
+// prices plane j % (SAH_SMALL_BINS-1) of axis j / (SAH_SMALL_BINS-1) by walking the segment, the cheapest plane wins
+// (lowest lane on a tie), ballots give the stable partition.  Open sub-ranges wait on a stack in LDS.
+__global__ __launch_bounds__(64) void k_sah_small(const SahSeg *__restrict__ small, int n, unsigned int *ord, const float4 *__restrict__ ref_lo,
+                                                  const float4 *__restrict__ ref_hi, int *scalars, int2 *children, int2 *range, int *parent)
+{
+    __shared__ float s_lo[3][64], s_hi[3][64];
+    __shared__ unsigned int s_ref[64];
+    __shared__ int s_stack[64][5];
+    constexpr int PLANES = SAH_SMALL_BINS - 1;
+    const int lane = threadIdx.x;
+    const SahSeg seg = small[blockIdx.x];
+    const int F = seg.first, m = seg.last - seg.first + 1;
+    if (m < 2 || m > 64 || F < 0 || seg.last >= n) return;
+    if (lane < m) {
+        const unsigned int r = ord[F + lane];
+        const float4 l = ref_lo[r], h = ref_hi[r];
+        s_ref[lane] = r;
+        s_lo[0][lane] = l.x; s_lo[1][lane] = l.y; s_lo[2][lane] = l.z;
+        s_hi[0][lane] = h.x; s_hi[1][lane] = h.y; s_hi[2][lane] = h.z;
+    }
+    if (lane == 0) { s_stack[0][0] = 0; s_stack[0][1] = m - 1; s_stack[0][2] = seg.parent; s_stack[0][3] = seg.side; s_stack[0][4] = seg.depth; }
+    int sp = 1;
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    while (sp > 0) {
+        sp--;
+        const int f = s_stack[sp][0], l = s_stack[sp][1], par = s_stack[sp][2], side = s_stack[sp][3], depth = s_stack[sp][4];
+        const int size = l - f + 1;
+        const bool in = lane >= f && lane <= l;
+        float cmin[3], cmax[3];
+        for (int a = 0; a < 3; a++) {
+            const float c = in ? 0.5f * (s_lo[a][lane] + s_hi[a][lane]) : 0.f;
+            float lo = in ? c : FLT_MAX, hi = in ? c : -FLT_MAX;
+            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+            cmin[a] = lo; cmax[a] = hi;
+        }
+        float cost = FLT_MAX;
+        if (lane < 3 * PLANES && depth + ceil_log2(size) < SAH_DEPTH_CAP) {
+            const int a = lane / PLANES, k = lane % PLANES;
+            const float alo = a == 0 ? cmin[0] : (a == 1 ? cmin[1] : cmin[2]), ahi = a == 0 ? cmax[0] : (a == 1 ? cmax[1] : cmax[2]);
+            float ll[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, lh[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            float rl[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, rh[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            int nl = 0;
+            for (int i = f; i <= l; i++) {
+                const bool left = sah_bin_of(0.5f * (s_lo[a][i] + s_hi[a][i]), alo, ahi, SAH_SMALL_BINS) <= k;
+                nl += left ? 1 : 0;
+                for (int q = 0; q < 3; q++) {
+                    const float bl = s_lo[q][i], bh = s_hi[q][i];
+                    ll[q] = fminf(ll[q], left ? bl : FLT_MAX); lh[q] = fmaxf(lh[q], left ? bh : -FLT_MAX);
+                    rl[q] = fminf(rl[q], left ? FLT_MAX : bl); rh[q] = fmaxf(rh[q], left ? -FLT_MAX : bh);
+                }
+            }
+            if (nl > 0 && nl < size) cost = half_area3(ll, lh) * (float)nl + half_area3(rl, rh) * (float)(size - nl);
+        }
+        float best = cost;
+        int who = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(best, off);
+            const int ow = __shfl_xor(who, off);
+            if (oc < best || (oc == best && ow < who)) { best = oc; who = ow; }
+        }
+        bool left;
+        if (best == FLT_MAX) {
+            left = lane - f < size / 2;
+        } else {
+            const int a = who / PLANES, k = who % PLANES;
+            const float alo = a == 0 ? cmin[0] : (a == 1 ? cmin[1] : cmin[2]), ahi = a == 0 ? cmax[0] : (a == 1 ? cmax[1] : cmax[2]);
+            left = in && sah_bin_of(0.5f * (s_lo[a][lane & 63] + s_hi[a][lane & 63]), alo, ahi, SAH_SMALL_BINS) <= k;
+        }
+        const unsigned long long mask = __ballot(in && left);
+        const int n_left = __popcll(mask), left_rank = __popcll(mask & lt_mask);
+        const int dest = left ? f + left_rank : f + n_left + (lane - f - left_rank);
+        float ml[3], mh[3];
+        unsigned int mr = 0;
+        if (in) {
+            for (int q = 0; q < 3; q++) { ml[q] = s_lo[q][lane]; mh[q] = s_hi[q][lane]; }
+            mr = s_ref[lane];
+        }
+        __syncthreads();
+        if (in) {
+            for (int q = 0; q < 3; q++) { s_lo[q][dest] = ml[q]; s_hi[q][dest] = mh[q]; }
+            s_ref[dest] = mr;
+        }
+        if (lane == 0) {
+            const int gamma = F + f + n_left - 1;
+            const int id = sah_node_id(par, gamma, scalars);
+            parent[id] = par;
+            range[id] = make_int2(F + f, F + l);
+            if (par >= 0) ((int *)(children + par))[side] = id;
+            for (int sd = 0; sd < 2; sd++) {
+                const int cf = sd == 0 ? f : f + n_left, cl = sd == 0 ? f + n_left - 1 : l;
+                if (cf == cl) {
+                    const int leaf = (n - 1) + F + cf;
+                    ((int *)(children + id))[sd] = leaf;
+                    parent[leaf] = id;
+                } else {
+                    const int t = sp + (sd == 1 && n_left > 1 ? 1 : 0);
+                    s_stack[t][0] = cf; s_stack[t][1] = cl; s_stack[t][2] = id; s_stack[t][3] = sd; s_stack[t][4] = depth + 1;
+                }
+            }
+        }
+        const bool open_l = n_left > 1, open_r = size - n_left > 1;
+        sp += (open_l ? 1 : 0) + (open_r ? 1 : 0);
+        __syncthreads();
+    }
+    if (lane < m) ord[F + lane] = s_ref[lane];
+}
 
 int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder, int split_cells, hipStream_t stream, LbvhResult *out,
                     std::string *err)
@@ -1332,28 +1657,81 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     }
     const int B = 256, G = blocks_for(n, B);
     int cur = 0;
-    const bool host_sah = builder == 3;
-    if (host_sah) {
-        std::vector<float4> h_lo((size_t)n), h_hi((size_t)n);
-        RT_HIP_CHECK(hipMemcpyAsync(h_lo.data(), ref_lo.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, stream), err);
-        RT_HIP_CHECK(hipMemcpyAsync(h_hi.data(), ref_hi.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, stream), err);
-        RT_HIP_CHECK(hipStreamSynchronize(stream), err);
-        HostSah hs;
-        hs.lo = h_lo.data(); hs.hi = h_hi.data();
-        hs.order.resize((size_t)n);
-        for (int k = 0; k < n; k++) hs.order[(size_t)k] = (unsigned)k;
-        hs.children.assign((size_t)n, make_int2(0, 0)); hs.range.assign((size_t)n, make_int2(0, 0));
-        hs.parent.assign(2 * (size_t)n, -1);
-        hs.build(0, n - 1, -1);
-        RT_HIP_CHECK(hipMemcpyAsync(vals[0].p, hs.order.data(), sizeof(unsigned int) * (size_t)n, hipMemcpyHostToDevice, stream), err);
-        RT_HIP_CHECK(hipMemcpyAsync(children.p, hs.children.data(), sizeof(int2) * (size_t)n, hipMemcpyHostToDevice, stream), err);
-        RT_HIP_CHECK(hipMemcpyAsync(range.p, hs.range.data(), sizeof(int2) * (size_t)n, hipMemcpyHostToDevice, stream), err);
-        RT_HIP_CHECK(hipMemcpyAsync(parent.p, hs.parent.data(), sizeof(int) * 2 * (size_t)n, hipMemcpyHostToDevice, stream), err);
-        RT_HIP_CHECK(hipStreamSynchronize(stream), err);       // the host vectors go out of scope
+    const bool sah = builder == 0 || builder == 3;
+    if (sah) {
+        // top-down binned SAH on the device: rounds over the long segments, then one wave per short segment
+        const int cap = n / (SAH_SMALL + 1) + 2, small_cap = n / 2 + 2;
+        DevBuf<int> seg_of[2], sc;
+        DevBuf<unsigned int> flag, scan, scan_tmp, cb[2];
+        DevBuf<SahSeg> act[2], small;
+        DevBuf<SahBin> bins;
+        DevBuf<SahCut> cut;
+        hipError_t e3 = hipSuccess;
+        auto A3 = [&](hipError_t r) { if (e3 == hipSuccess) e3 = r; };
+        A3(seg_of[0].alloc(n)); A3(seg_of[1].alloc(n)); A3(sc.alloc(4)); A3(flag.alloc(n)); A3(scan.alloc(n));
+        A3(scan_tmp.alloc((size_t)blocks_for(n, SCAN_CHUNK) + 1)); A3(cb[0].alloc(6 * (size_t)cap)); A3(cb[1].alloc(6 * (size_t)cap));
+        A3(act[0].alloc(cap)); A3(act[1].alloc(cap)); A3(small.alloc(small_cap)); A3(bins.alloc((size_t)cap * 3 * SAH_BINS)); A3(cut.alloc(cap));
+        if (e3 != hipSuccess) {
+            if (err) *err = std::string("SAH builder allocation: ") + hipGetErrorString(e3);
+            return RT_E_NOMEM;
+        }
+        RT_HIP_CHECK(hipMemsetAsync(sc.p, 0, 4 * sizeof(int), stream), err);
+        hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, cb[0].p);
+        SahSeg root_seg;
+        root_seg.first = 0; root_seg.last = n - 1; root_seg.parent = -1; root_seg.side = 0; root_seg.depth = 0;
+        int n_act = n > SAH_SMALL ? 1 : 0, n_small = n_act ? 0 : 1;
+        RT_HIP_CHECK(hipMemcpyAsync(n_act ? act[0].p : small.p, &root_seg, sizeof root_seg, hipMemcpyHostToDevice, stream), err);
+        if (!n_act) {
+            RT_HIP_CHECK(hipMemcpyAsync(sc.p + 2, &n_small, sizeof(int), hipMemcpyHostToDevice, stream), err);
+        }
+        hipLaunchKernelGGL(k_sah_init, dim3(G < 1024 ? G : 1024), dim3(256), 0, stream, ref_lo.p, ref_hi.p, n, n_act ? 0 : -1, vals[0].p, seg_of[0].p,
+                           cb[0].p);
+        int a_cur = 0;
+        for (int round = 0; n_act > 0; round++) {
+            if (round > 64) {
+                if (err) *err = "SAH builder: the rounds do not end";
+                return RT_E_DEVICE;
+            }
+            hipLaunchKernelGGL(k_sah_clear, dim3(blocks_for(n_act * 3 * SAH_BINS, B)), dim3(B), 0, stream, bins.p, n_act * 3 * SAH_BINS);
+            hipLaunchKernelGGL(k_sah_bin, dim3(G), dim3(256), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, cb[a_cur].p, n_act, bins.p);
+            RT_HIP_CHECK(hipMemsetAsync(sc.p + 1, 0, sizeof(int), stream), err);
+            hipLaunchKernelGGL(k_sah_split, dim3(blocks_for(n_act, 64)), dim3(64), 0, stream, act[a_cur].p, n_act, bins.p, n, children.p, range.p,
+                               parent.p, sc.p, small.p, act[a_cur ^ 1].p, cap, cb[a_cur ^ 1].p, cut.p);
+            hipLaunchKernelGGL(k_sah_flag, dim3(G), dim3(B), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, act[a_cur].p, n_act,
+                               cb[a_cur].p, cut.p, flag.p, scan.p);
+            scan_exclusive<unsigned int>(scan.p, n, (unsigned int *)nullptr, scan_tmp.p, stream);
+            hipLaunchKernelGGL(k_sah_scatter, dim3(G), dim3(256), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, act[a_cur].p, n_act,
+                               cut.p, flag.p, scan.p, vals[cur ^ 1].p, seg_of[a_cur ^ 1].p, cb[a_cur ^ 1].p);
+            int counts2[2] = { 0, 0 };
+            RT_HIP_CHECK(hipMemcpyAsync(counts2, sc.p + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, stream), err);
+            RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+            if (counts2[0] < 0 || counts2[0] > cap || counts2[1] < 0 || counts2[1] > small_cap) {
+                if (err) *err = "SAH builder: segment count out of range";
+                return RT_E_DEVICE;
+            }
+            n_act = counts2[0];
+            n_small = counts2[1];
+            cur ^= 1;
+            a_cur ^= 1;
+        }
+        if (n_small > 0)
+            hipLaunchKernelGGL(k_sah_small, dim3(n_small), dim3(64), 0, stream, small.p, n, vals[cur].p, ref_lo.p, ref_hi.p, sc.p, children.p,
+                               range.p, parent.p);
+        // a malformed tree would send the level-by-level passes below (and every ray later) astray: check it
+        RT_HIP_CHECK(hipMemsetAsync(depth.p, 0, sizeof(int) * (size_t)n, stream), err);
+        hipLaunchKernelGGL(k_tree_check, dim3(G), dim3(B), 0, stream, children.p, range.p, parent.p, vals[cur].p, n, depth.p, sc.p + 3);
+        int bad = 0;
+        RT_HIP_CHECK(hipGetLastError(), err);
+        RT_HIP_CHECK(hipMemcpyAsync(&bad, sc.p + 3, sizeof(int), hipMemcpyDeviceToHost, stream), err);
+        RT_HIP_CHECK(hipStreamSynchronize(stream), err);       // also: the work arrays go out of scope
+        if (bad) {
+            if (err) *err = "SAH builder: the tree failed its check (" + std::to_string(bad) + " violations)";
+            return RT_E_DEVICE;
+        }
     } else {
         hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, n, bounds.p, keys[0].p, vals[0].p);
     }
-    for (int pass = 0; pass < 8 && !host_sah; pass++) {
+    for (int pass = 0; pass < 8 && !sah; pass++) {
         int shift = pass * 8;
         hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(64), 0, stream, keys[cur].p, n, shift, hist.p, n_tiles);
         scan_exclusive<unsigned int>(hist.p, 256 * n_tiles, (unsigned int *)nullptr, scan_u32.p, stream);
@@ -1364,18 +1742,22 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
-    const bool ploc = builder != 1 && !host_sah;
+    const bool ploc = builder != 1 && !sah;
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
     DevBuf<unsigned long long> flags, totals;
     hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, stream, ref_lo.p, ref_hi.p, vals[cur].p, n, bounds.p, box_lo.p, box_hi.p);
     if (!ploc) {
-        if (!host_sah)
+        if (!sah)
             hipLaunchKernelGGL(k_karras, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, keys[cur].p, n, children.p, range.p,
                                parent.p);
         hipLaunchKernelGGL(k_node_depth, dim3(min(blocks_for(n - 1, 256), 2048)), dim3(256), 0, stream, parent.p, n - 1, depth.p, scalars.p);
         RT_HIP_CHECK(hipMemcpyAsync(&max_depth, scalars.p, sizeof(int), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipStreamSynchronize(stream), err);
+        if (max_depth > 4096) {
+            if (err) *err = "hierarchy deeper than 4096 levels";
+            return RT_E_LIMIT;
+        }
         for (int level = max_depth; level >= 0; level--)
             hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, depth.p, n - 1, level,
                                box_lo.p, box_hi.p);
@@ -1436,10 +1818,10 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, parent.p, depth.p, n,
                        leaf_max, box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre.p, out->nodes,
                        grid.p, scalars.p + 1);
-    DevBuf<double> sah;
-    if (sah.alloc(1) == hipSuccess) {
-        RT_HIP_CHECK(hipMemsetAsync(sah.p, 0, sizeof(double), stream), err);
-        hipLaunchKernelGGL(k_sah_cost, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, n, leaf_max, box_lo.p, box_hi.p, sah.p);
+    DevBuf<double> sah_acc;
+    if (sah_acc.alloc(1) == hipSuccess) {
+        RT_HIP_CHECK(hipMemsetAsync(sah_acc.p, 0, sizeof(double), stream), err);
+        hipLaunchKernelGGL(k_sah_cost, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, children.p, range.p, n, leaf_max, box_lo.p, box_hi.p, sah_acc.p);
     }
     DevBuf<int> wide, pre4, root, slot;
     DevBuf<int4> wkids;
@@ -1478,8 +1860,8 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     RT_HIP_CHECK(hipMemcpyAsync(&out->grid, grid.p, sizeof(QuantGrid), hipMemcpyDeviceToHost, stream), err);
     double sah_sum = 0.0;
     float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = root_lo;
-    if (sah.p) {
-        RT_HIP_CHECK(hipMemcpyAsync(&sah_sum, sah.p, sizeof(double), hipMemcpyDeviceToHost, stream), err);
+    if (sah_acc.p) {
+        RT_HIP_CHECK(hipMemcpyAsync(&sah_sum, sah_acc.p, sizeof(double), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipMemcpyAsync(&root_lo, box_lo.p, sizeof(float4), hipMemcpyDeviceToHost, stream), err);
         RT_HIP_CHECK(hipMemcpyAsync(&root_hi, box_hi.p, sizeof(float4), hipMemcpyDeviceToHost, stream), err);
     }

@@ -64,7 +64,7 @@ def test_sponza_1080p_properties(sponza):
     assert sz["rays_shadow"] <= s1["rays_shadow"] <= sa["rays_shadow"] and s1["rays_reflect"] <= sa["rays_reflect"]
 
 
-@pytest.mark.parametrize("builder", [rt.BUILDER_PLOC, rt.BUILDER_LBVH])
+@pytest.mark.parametrize("builder", [rt.BUILDER_SAH, rt.BUILDER_PLOC, rt.BUILDER_LBVH])
 def test_second_stand_in_1080p_equals_cpu_oracle_and_linear_scan_lattice(builder):
     """The irregular stand-in (two-triangle walls beside 50k-triangle ornaments, slivers, overlapping cloth): the
     full 1080p frame against the oracle's own BVH, and a lattice against the oracle's brute-force scan (the

@@ -15,7 +15,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from common import (GOLDEN, O, ROOT, atrium_spec, compare, cube_spec, golden_cases, lcg_floats, ocam, rt, scenes, soup_spec,
+from common import (GOLDEN, O, ROOT, SceneSpec, atrium_spec, compare, cube_spec, golden_cases, lcg_floats, ocam, rt, scenes, soup_spec,
                     stock_analytic, stock_spec, to_oracle, to_product)
 
 pytestmark = pytest.mark.gpu
@@ -312,7 +312,7 @@ def test_tiny_meshes_through_every_hierarchy_shape(n_tris):
     W, H, D = 160, 120, 3
     base = render(spec, W, H, D, cam, rt.ACCEL_LINEAR)
     assert_parity(compare(base, to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam))))
-    for builder in (rt.BUILDER_LBVH, rt.BUILDER_PLOC):
+    for builder in (rt.BUILDER_LBVH, rt.BUILDER_PLOC, rt.BUILDER_SAH):
         for leaf_max in (1, 2, 8):
             for pipeline in (rt.PIPELINE_FUSED, rt.PIPELINE_WAVEFRONT):
                 with rt.Context(0) as ctx:
@@ -330,6 +330,50 @@ def test_tiny_meshes_through_every_hierarchy_shape(n_tris):
                 assert rays(st) == rays(base["stats"])
 
 
+def _sah_case(kind):
+    """Meshes that send the surface-area-heuristic builder down each of its paths."""
+    if kind.startswith("soup"):
+        return soup_spec(int(kind[4:]), seed=int(kind[4:]))
+    base = soup_spec(1, seed=5)
+    tri = base.verts[:3]
+    if kind == "stack":            # 300 copies of one triangle: every centroid equal, no plane separates anything
+        verts = np.tile(tri, (300, 1))
+    else:                          # "ladder": spacing grows by powers of two, so every cheapest cut peels off one end
+        n = 90
+        shift = np.zeros((n, 3), np.float32)
+        shift[:, 0] = (2.0 ** (np.arange(n) * 0.25) - 1.0) * 0.01
+        verts = (tri[None] * 0.05 + np.array([-3.5, 0.0, 2.0], np.float32) + shift[:, None, :]).reshape(-1, 3)
+    n_tris = len(verts) // 3
+    return SceneSpec(base.analytic, verts, np.arange(n_tris * 3, dtype=np.int32), mats=base.mats,
+                     tri_material=(np.arange(n_tris) % 4).astype(np.int32))
+
+
+@pytest.mark.parametrize("kind", ["soup63", "soup64", "soup65", "soup66", "soup129", "soup1000", "soup20000", "stack", "ladder"])
+def test_sah_builder_on_every_path_equals_linear_scan(kind):
+    """The top-down builder has two regimes (rounds over the whole grid above 64 references, one wave per segment
+    below) and two kinds of cut (a plane, or the middle of the range when no plane separates the centroids or the tree
+    grows too deep).  Sizes either side of the regime boundary, identical triangles and a mesh that peels one
+    triangle per cut: each frame equals the linear scan bit for bit, with the same ray counts."""
+    spec = _sah_case(kind)
+    cam = rt.Camera(pitch=0.05)
+    W, H, D = 160, 120, 3
+    base = render(spec, W, H, D, cam, rt.ACCEL_LINEAR)
+    for leaf_max in (1, 2):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+            ctx.set_option(rt.OPT_BUILDER, rt.BUILDER_SAH)
+            ctx.set_option(rt.OPT_LEAF_MAX, leaf_max)
+            ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_WAVEFRONT)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            g = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+        assert st["accel"] == 1 and 0 < st["bvh_depth"] <= 64 and st["bvh_sah_cost"] > 0
+        for k in ("rgb8", "hit_id", "rgb32"):
+            assert np.array_equal(g[k].view(np.uint8), base[k].view(np.uint8)), (k, kind, leaf_max)
+        assert rays(st) == rays(base["stats"])
+
+
 # ------------------------------------------------------------------ moving geometry (refit)
 def _moved(verts, step):
     """A deformation that changes the scene bounds: a swell along x and a shear in y, growing with step."""
@@ -340,7 +384,7 @@ def _moved(verts, step):
     return v.astype(np.float32)
 
 
-@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC])
+@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC, rt.BUILDER_SAH])
 @pytest.mark.parametrize("flat", [False, True])
 def test_refit_after_vertex_updates_equals_a_fresh_build_and_the_oracle(builder, flat):
     """rt_update_mesh_vertices / rt_update_triangles keep the tree and refit its boxes: every frame
@@ -930,7 +974,7 @@ def sphere_(p, r, light, col):
     return dict(kind="sphere", p=p, s=r, mat=(0.0, 1.0, 1.0, col), is_light=light)
 
 
-@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC])
+@pytest.mark.parametrize("builder", [rt.BUILDER_LBVH, rt.BUILDER_PLOC, rt.BUILDER_SAH])
 def test_cut_triangle_references_change_the_tree_and_nothing_else(builder):
     """RT_OPT_SPLIT: large triangles enter the hierarchy as several references with clipped boxes.  The frame (ids,
     colours, ray counts) must equal the uncut hierarchy's and the oracle's brute-force scan; only the tree grows and
