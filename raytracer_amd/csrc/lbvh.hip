@@ -1207,47 +1207,77 @@ __device__ __forceinline__ void sah_bin_add(SahBin *b, const float4 l, const flo
     atomicMax(&b->hi[0], float_to_ordered(h.x)); atomicMax(&b->hi[1], float_to_ordered(h.y)); atomicMax(&b->hi[2], float_to_ordered(h.z));
 }
 
-// Segments are contiguous, so a block whose first and last position name the same segment lies inside it.
+// Which of the block's open segments a position belongs to.  Segments are contiguous and longer than SAH_SMALL, so
+// the 256 positions of a block meet at most SAH_BLOCK_SEGS of them; the k-th one in position order gets local index k
+// and s_slot[k] = its slot in the round's segment list.  Returns -1 for a position in no open segment; a local index
+// >= SAH_BLOCK_SEGS (cannot happen) sends the caller to the global arrays.  Two barriers; every thread must call it.
+constexpr int SAH_BLOCK_SEGS = 256 / (SAH_SMALL + 1) + 2;
+
+__device__ __forceinline__ int sah_local_segment(const int *__restrict__ seg_of, int p, int n, int n_act, int *s_wave, int *s_slot, int &seg,
+                                                 int &n_local)
+{
+    const int t = threadIdx.x;
+    int s = -1, prev = -2;
+    if (p < n) {
+        s = seg_of[p];
+        if (s >= n_act) s = -1;
+        if (t > 0) {
+            prev = seg_of[p - 1];
+            if (prev >= n_act) prev = -1;
+        }
+    }
+    const bool head = s >= 0 && s != prev;
+    const unsigned long long mask = __ballot(head);
+    if ((t & 63) == 0) s_wave[t >> 6] = (int)__popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+        const int c = s_wave[w];
+        if (w < (t >> 6)) before += c;
+        total += c;
+    }
+    const int local = before + (int)__popcll(mask & ((2ull << (t & 63)) - 1ull)) - 1;
+    if (head && local < SAH_BLOCK_SEGS) s_slot[local] = s;
+    __syncthreads();
+    seg = s;
+    n_local = total < SAH_BLOCK_SEGS ? total : SAH_BLOCK_SEGS;
+    return s >= 0 ? local : -1;
+}
+
+// Every reference of an open segment into one bin per axis.  The block collects in LDS and adds each non-empty bin to
+// the segment's global bins once (direct atomics from every thread ran at ~24 G per second and made this kernel most
+// of the build).
 __global__ __launch_bounds__(256) void k_sah_bin(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n,
                                                  const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi,
                                                  const unsigned int *__restrict__ cb, int n_act, SahBin *bins)
 {
-    __shared__ SahBin s_bin[3 * SAH_BINS];
-    const int p0 = blockIdx.x * 256, p1 = min(p0 + 255, n - 1);
-    const int s0 = seg_of[p0];
-    const bool same = s0 >= 0 && s0 == seg_of[p1];
-    if (same) {
-        if (threadIdx.x < 3 * SAH_BINS) {
-            SahBin b;
-            b.count = 0;
-            for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
-            s_bin[threadIdx.x] = b;
-        }
-        __syncthreads();
+    __shared__ SahBin s_bin[SAH_BLOCK_SEGS * 3 * SAH_BINS];
+    __shared__ int s_wave[4], s_slot[SAH_BLOCK_SEGS];
+    for (int e = threadIdx.x; e < SAH_BLOCK_SEGS * 3 * SAH_BINS; e += 256) {
+        SahBin b;
+        b.count = 0;
+        for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
+        s_bin[e] = b;
     }
-    const int p = p0 + threadIdx.x;
-    if (p < n) {
-        const int s = seg_of[p];
-        if (s >= 0 && s < n_act) {
-            const unsigned int r = ord[p];
-            const float4 l = ref_lo[r], h = ref_hi[r];
-            const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
-            for (int a = 0; a < 3; a++) {
-                const int b = sah_bin_of(c[a], ordered_to_float(cb[6 * s + a]), ordered_to_float(cb[6 * s + 3 + a]), SAH_BINS);
-                sah_bin_add(same ? &s_bin[a * SAH_BINS + b] : &bins[((size_t)s * 3 + a) * SAH_BINS + b], l, h);
-            }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int s, n_local;
+    const int local = sah_local_segment(seg_of, p, n, n_act, s_wave, s_slot, s, n_local);     // its barriers also order the clearing above
+    if (local >= 0) {
+        const unsigned int r = ord[p];
+        const float4 l = ref_lo[r], h = ref_hi[r];
+        const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
+        for (int a = 0; a < 3; a++) {
+            const int b = sah_bin_of(c[a], ordered_to_float(cb[6 * s + a]), ordered_to_float(cb[6 * s + 3 + a]), SAH_BINS);
+            sah_bin_add(local < SAH_BLOCK_SEGS ? &s_bin[(local * 3 + a) * SAH_BINS + b] : &bins[((size_t)s * 3 + a) * SAH_BINS + b], l, h);
         }
     }
-    if (same) {
-        __syncthreads();
-        if (threadIdx.x < 3 * SAH_BINS && s0 < n_act) {
-            const SahBin b = s_bin[threadIdx.x];
-            if (b.count) {
-                SahBin *g = &bins[(size_t)s0 * 3 * SAH_BINS + threadIdx.x];
-                atomicAdd(&g->count, b.count);
-                for (int k = 0; k < 3; k++) { atomicMin(&g->lo[k], b.lo[k]); atomicMax(&g->hi[k], b.hi[k]); }
-            }
-        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_local * 3 * SAH_BINS; e += 256) {
+        const SahBin b = s_bin[e];
+        if (!b.count) continue;
+        SahBin *g = &bins[(size_t)s_slot[e / (3 * SAH_BINS)] * 3 * SAH_BINS + e % (3 * SAH_BINS)];
+        atomicAdd(&g->count, b.count);
+        for (int k = 0; k < 3; k++) { atomicMin(&g->lo[k], b.lo[k]); atomicMax(&g->hi[k], b.hi[k]); }
     }
 }
 
@@ -1283,48 +1313,57 @@ __device__ int sah_child(int id, int side, int first, int last, int depth, int n
     return k;
 }
 
-__global__ void k_sah_split(const SahSeg *__restrict__ act, int n_act, const SahBin *__restrict__ bins, int n, int2 *children, int2 *range,
-                            int *parent, int *scalars /*0 root gamma, 1 segments of the next round, 2 small segments*/, SahSeg *small,
-                            SahSeg *next, int next_cap, unsigned int *cb_next, SahCut *cut)
+// One wave per open segment.  Lane b holds bin b of the axis at hand; inclusive scans by shuffles give the box and
+// count of bins 0..b (from below) and b..31 (from above), lane b < 31 prices the plane between bins b and b + 1, a
+// shuffle reduction keeps the cheapest (lowest axis, then lowest bin on a tie).
+__global__ __launch_bounds__(64) void k_sah_split(const SahSeg *__restrict__ act, int n_act, const SahBin *__restrict__ bins, int n, int2 *children,
+                                                  int2 *range, int *parent, int *scalars /*0 root gamma, 1 segments of the next round, 2 small segments*/,
+                                                  SahSeg *small, SahSeg *next, int next_cap, unsigned int *cb_next, SahCut *cut)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    static_assert(SAH_BINS == 32, "one half-wave of lanes per axis sweep");
+    const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= n_act) return;
     const SahSeg seg = act[s];
     const int size = seg.last - seg.first + 1;
     float best = FLT_MAX;
-    int axis = -1, bin = 0, n_left = size / 2;
+    int best_key = 0x7fffffff, best_left = 0;           // key = axis * 32 + bin
     if (seg.depth + ceil_log2(size) < SAH_DEPTH_CAP) {
+        const int b = lane & 31;
+        const bool up = lane < 32;                      // lanes 0..31 scan from bin 0 upward, lanes 32..63 from bin 31 downward
         for (int a = 0; a < 3; a++) {
-            const SahBin *B = bins + ((size_t)s * 3 + a) * SAH_BINS;
-            float right_cost[SAH_BINS];
-            {
-                float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-                unsigned int c = 0;
-#pragma unroll
-                for (int b = SAH_BINS - 1; b > 0; b--) {
-                    const SahBin q = B[b];
-                    if (q.count) {
-                        for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], ordered_to_float(q.lo[k])); h[k] = fmaxf(h[k], ordered_to_float(q.hi[k])); }
-                        c += q.count;
-                    }
-                    right_cost[b] = c ? half_area3(l, h) * (float)c : 0.f;
+            const SahBin q = bins[((size_t)s * 3 + a) * SAH_BINS + (up ? b : 31 - b)];
+            float l[3], h[3];
+            int c = (int)q.count;
+            for (int k = 0; k < 3; k++) {
+                l[k] = q.count ? ordered_to_float(q.lo[k]) : FLT_MAX;
+                h[k] = q.count ? ordered_to_float(q.hi[k]) : -FLT_MAX;
+            }
+            for (int off = 1; off < 32; off <<= 1) {            // inclusive scan inside each half-wave
+                const int oc = __shfl_up(c, off, 32);
+                float ol[3], oh[3];
+                for (int k = 0; k < 3; k++) { ol[k] = __shfl_up(l[k], off, 32); oh[k] = __shfl_up(h[k], off, 32); }
+                if (b >= off) {
+                    c += oc;
+                    for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], ol[k]); h[k] = fmaxf(h[k], oh[k]); }
                 }
             }
-            float l[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, h[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-            unsigned int c = 0;
-#pragma unroll
-            for (int b = 0; b + 1 < SAH_BINS; b++) {
-                const SahBin q = B[b];
-                if (q.count) {
-                    for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], ordered_to_float(q.lo[k])); h[k] = fmaxf(h[k], ordered_to_float(q.hi[k])); }
-                    c += q.count;
-                }
-                if (c == 0 || c >= (unsigned)size) continue;
-                const float cost = half_area3(l, h) * (float)c + right_cost[b + 1];
-                if (cost < best) { best = cost; axis = a; bin = b; n_left = (int)c; }
+            const float part = c > 0 ? half_area3(l, h) * (float)c : 0.f;
+            // plane after bin b: lower part = upward scan at b (lane b), upper part = downward scan at 30 - b (lane 32 + 30 - b)
+            const float upper = __shfl(part, 32 + (30 - b < 0 ? 0 : 30 - b));
+            if (up && b < 31 && c > 0 && c < size) {
+                const float cost = part + upper;
+                if (cost < best) { best = cost; best_key = a * 32 + b; best_left = c; }
             }
         }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(best, off);
+            const int ok = __shfl_xor(best_key, off), ol = __shfl_xor(best_left, off);
+            if (oc < best || (oc == best && ok < best_key)) { best = oc; best_key = ok; best_left = ol; }
+        }
     }
+    if (lane != 0) return;
+    const int axis = best == FLT_MAX ? -1 : best_key >> 5, bin = best == FLT_MAX ? 0 : best_key & 31;
+    const int n_left = best == FLT_MAX ? size / 2 : best_left;
     const int gamma = seg.first + n_left - 1;
     const int id = sah_node_id(seg.parent, gamma, scalars);
     parent[id] = seg.parent;
@@ -1360,26 +1399,23 @@ __global__ void k_sah_flag(const unsigned int *__restrict__ ord, const int *__re
     scan[p] = left;
 }
 
-// scan = exclusive prefix sums of flag.  The partition is stable: both halves keep their order.
+// scan = exclusive prefix sums of flag.  The partition is stable: both halves keep their order.  The children's
+// centroid bounds are collected per block in LDS (two children per open segment the block meets) and added once.
 __global__ __launch_bounds__(256) void k_sah_scatter(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n,
                                                      const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi,
                                                      const SahSeg *__restrict__ act, int n_act, const SahCut *__restrict__ cut,
                                                      const unsigned int *__restrict__ flag, const unsigned int *__restrict__ scan,
                                                      unsigned int *ord_next, int *seg_next, unsigned int *cb_next)
 {
-    __shared__ unsigned int s_cb[2][6];
-    const int p0 = blockIdx.x * 256, p1 = min(p0 + 255, n - 1);
-    const int s0 = seg_of[p0];
-    const bool same = s0 >= 0 && s0 < n_act && s0 == seg_of[p1];
-    if (same) {
-        if (threadIdx.x < 12) s_cb[threadIdx.x / 6][threadIdx.x % 6] = threadIdx.x % 6 < 3 ? 0xffffffffu : 0u;
-        __syncthreads();
-    }
-    const int p = p0 + threadIdx.x;
+    __shared__ unsigned int s_cb[SAH_BLOCK_SEGS * 2 * 6];
+    __shared__ int s_wave[4], s_slot[SAH_BLOCK_SEGS];
+    if (threadIdx.x < SAH_BLOCK_SEGS * 12) s_cb[threadIdx.x] = threadIdx.x % 6 < 3 ? 0xffffffffu : 0u;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int s, n_local;
+    const int local = sah_local_segment(seg_of, p, n, n_act, s_wave, s_slot, s, n_local);
     if (p < n) {
-        const int s = seg_of[p];
         const unsigned int r = ord[p];
-        if (s < 0 || s >= n_act) {
+        if (local < 0) {
             ord_next[p] = r;
             seg_next[p] = -1;
         } else {
@@ -1394,22 +1430,20 @@ __global__ __launch_bounds__(256) void k_sah_scatter(const unsigned int *__restr
             if (slot >= 0) {
                 const float4 l = ref_lo[r], h = ref_hi[r];
                 const unsigned int cl[3] = { float_to_ordered(0.5f * (l.x + h.x)), float_to_ordered(0.5f * (l.y + h.y)), float_to_ordered(0.5f * (l.z + h.z)) };
-                unsigned int *dst = same ? s_cb[left ? 0 : 1] : cb_next + 6 * (size_t)slot;
+                unsigned int *dst = local < SAH_BLOCK_SEGS ? &s_cb[(local * 2 + (left ? 0 : 1)) * 6] : cb_next + 6 * (size_t)slot;
                 for (int a = 0; a < 3; a++) { atomicMin(&dst[a], cl[a]); atomicMax(&dst[3 + a], cl[a]); }
             }
         }
     }
-    if (same) {
-        __syncthreads();
-        if (threadIdx.x < 12) {
-            const int side = threadIdx.x / 6, k = threadIdx.x % 6;
-            const SahCut c = cut[s0];
-            const int slot = side == 0 ? c.slot_left : c.slot_right;
-            const unsigned int v = s_cb[side][k];
-            if (slot >= 0 && v != (k < 3 ? 0xffffffffu : 0u)) {
-                if (k < 3) atomicMin(&cb_next[6 * (size_t)slot + k], v);
-                else atomicMax(&cb_next[6 * (size_t)slot + k], v);
-            }
+    __syncthreads();
+    if (threadIdx.x < n_local * 12) {
+        const int k = threadIdx.x % 6, side = (threadIdx.x / 6) & 1;
+        const SahCut c = cut[s_slot[threadIdx.x / 12]];
+        const int slot = side == 0 ? c.slot_left : c.slot_right;
+        const unsigned int v = s_cb[threadIdx.x];
+        if (slot >= 0 && v != (k < 3 ? 0xffffffffu : 0u)) {
+            if (k < 3) atomicMin(&cb_next[6 * (size_t)slot + k], v);
+            else atomicMax(&cb_next[6 * (size_t)slot + k], v);
         }
     }
 }
@@ -1695,7 +1729,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
             hipLaunchKernelGGL(k_sah_clear, dim3(blocks_for(n_act * 3 * SAH_BINS, B)), dim3(B), 0, stream, bins.p, n_act * 3 * SAH_BINS);
             hipLaunchKernelGGL(k_sah_bin, dim3(G), dim3(256), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, cb[a_cur].p, n_act, bins.p);
             RT_HIP_CHECK(hipMemsetAsync(sc.p + 1, 0, sizeof(int), stream), err);
-            hipLaunchKernelGGL(k_sah_split, dim3(blocks_for(n_act, 64)), dim3(64), 0, stream, act[a_cur].p, n_act, bins.p, n, children.p, range.p,
+            hipLaunchKernelGGL(k_sah_split, dim3(n_act), dim3(64), 0, stream, act[a_cur].p, n_act, bins.p, n, children.p, range.p,
                                parent.p, sc.p, small.p, act[a_cur ^ 1].p, cap, cb[a_cur ^ 1].p, cut.p);
             hipLaunchKernelGGL(k_sah_flag, dim3(G), dim3(B), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, act[a_cur].p, n_act,
                                cb[a_cur].p, cut.p, flag.p, scan.p);
