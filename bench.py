@@ -238,6 +238,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name, "triangles": wl.n_tris, "resolution": [wl.W, wl.H], "bounces": wl.max_depth,
                        "accel": "lbvh" if st["accel"] else "linear", "bvh_depth": st["bvh_depth"],
+                       "builder": {0: "binned SAH", 1: "Karras LBVH", 2: "PLOC", 3: "binned SAH"}[a.builder] if st["accel"] else "none",
+                       "bvh_sah_cost": round(st["bvh_sah_cost"], 2), "bvh_refs": st["bvh_refs"],
                        "leaf_max": st["bvh_leaf_max"], "partition": "%d-row bands round-robin" % a.band_rows if world > 1 else "none",
                        "rays_per_frame": {"primary": rp, "shadow": rs, "reflect": rr}},
             "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
