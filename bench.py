@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames a rank keeps in flight (one context and stream each); 0 = 1 on one GPU, 4 when the frame is partitioned")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch of every frame instead of replaying a hipGraph")
     ap.add_argument("--builder", type=int, default=0, help="0 auto (= 3), 1 Karras LBVH, 2 PLOC, 3 binned SAH")
     ap.add_argument("--lib", default="", help="another build of librt_amd.so to load (A/B runs of kernel variants)")
@@ -92,17 +94,23 @@ def timed_frames(render, sync, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def share_table(ctx, wl, band_rows, torch, dev, steps=10):
+def share_table(ctxs, wl, band_rows, torch, dev, steps=10):
     """One rank's share of the frame, measured on this GPU: part 0 of 1, 2, 4 and 8 parts (16-row bands
-    round-robin), graph replay, RGB8 only, ms per frame.  What strong scaling can reach before the gather."""
+    round-robin), graph replay, RGB8 only, ms per frame, with len(ctxs) frames in flight (one context, stream and
+    buffer each, frames round-robin).  What strong scaling can reach before the gather."""
     import raytracer_amd as rt
     out = {}
-    buf = torch.zeros((wl.H, wl.W, 3), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.Stream(device=dev)
+    slots = [(c, torch.zeros((wl.H, wl.W, 3), dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev)) for c in ctxs]
     for parts in (1, 2, 4, 8):
         rs = rt.band_rowset(wl.H, band_rows, 0, parts) if parts > 1 else rt.RowSet(0, 1, 1, wl.H)
-        render = lambda: ctx.render_rows_device(wl.W, wl.H, rs, wl.max_depth, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
-        out[str(parts)] = timed_frames(render, torch.cuda.synchronize, steps, 3)
+        turn = [0]
+
+        def render():
+            c, buf, stream = slots[turn[0] % len(slots)]
+            turn[0] += 1
+            c.render_rows_device(wl.W, wl.H, rs, wl.max_depth, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+
+        out[str(parts)] = timed_frames(render, torch.cuda.synchronize, steps * len(slots), 3 * len(slots))
     return out
 
 
@@ -159,17 +167,26 @@ def main():
             raise SystemExit("--obj needs an existing file and the sponza workload")
     wl = workloads.by_name(a.workload, **kw)
 
-    ctx = rt.Context(local_rank)
-    if a.leaf_max:
-        ctx.set_option(rt.OPT_LEAF_MAX, a.leaf_max)
-    if a.pipeline:
-        ctx.set_option(rt.OPT_PIPELINE, a.pipeline)
-    if a.builder:
-        ctx.set_option(rt.OPT_BUILDER, a.builder)
-    if a.no_graph:
-        ctx.set_option(rt.OPT_GRAPH, 0)
-    wl.load(ctx)
-    pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
+    def make_context():
+        c = rt.Context(local_rank)
+        if a.leaf_max:
+            c.set_option(rt.OPT_LEAF_MAX, a.leaf_max)
+        if a.pipeline:
+            c.set_option(rt.OPT_PIPELINE, a.pipeline)
+        if a.builder:
+            c.set_option(rt.OPT_BUILDER, a.builder)
+        if a.no_graph:
+            c.set_option(rt.OPT_GRAPH, 0)
+        wl.load(c)
+        return c
+
+    # One rank's share of a partitioned frame leaves most of the GPU idle (fewer rays than lanes, six dependent launches
+    # each as long as its longest rays), so a partitioned job keeps several frames in flight: one context, stream and
+    # buffer set per frame slot.  On one GPU the whole frame fills the chip and one slot is enough.
+    in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (1 if world == 1 else 4)
+    ctxs = [make_context() for _ in range(in_flight)]
+    ctx = ctxs[0]
+    pr = PartitionedRenderer(ctxs, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -179,19 +196,51 @@ def main():
 
     # the timed loop runs without per-launch device events, so that an unchanged frame replays as one
     # hipGraph; kernel times come from one more frame with the events on, outside the timed region
-    # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
-    ctx.set_option(rt.OPT_TIMING, 0)
+    for c in ctxs:
+        c.set_option(rt.OPT_TIMING, 0)
+    frame_latency_ms = None
+    if in_flight == 1:
+        # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
+        with torch.cuda.stream(pr.stream):
+            for _ in range(a.warmup):
+                pr.render()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                pr.render()
+            sync_all()
+            dt = time.perf_counter() - t0
+    else:
+        # Frames go to the slots round-robin; the consumer of a frame (here: nothing but the wait) runs in_flight - 1
+        # frames behind the producer, as a display or an encoder would.
+        from collections import deque
+        pending = deque()
+
+        def step():
+            pending.append(pr.render_async())
+            if len(pending) >= in_flight:
+                pending.popleft().wait()
+
+        def drain():
+            while pending:
+                pending.popleft().wait()
+
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            for _ in range(a.warmup * in_flight):
+                step()
+            drain()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            drain()
+            sync_all()
+            dt = time.perf_counter() - t0
+            # the same frames one at a time: what one frame takes from request to result
+            frame_latency_ms = timed_frames(pr.render, sync_all, min(a.steps, 20), 2)
     with torch.cuda.stream(pr.stream):
-        for _ in range(a.warmup):
-            pr.render()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            pr.render()
-        sync_all()
-        dt = time.perf_counter() - t0
         ctx.set_option(rt.OPT_TIMING, 1)
-        pr.render()
+        pr.render(slot=0)
         sync_all()
     st = ctx.stats()   # one frame of this rank: ray counts + device-event kernel times
 
@@ -207,7 +256,7 @@ def main():
     # algorithmic flops from a counting pass outside the timed region, duration from the
     # device events the library records around those launches on the launch stream.
     ctx.set_option(rt.OPT_COUNT_TESTS, 1)
-    pr.render()
+    pr.render(slot=0)
     sync_all()
     cst = ctx.stats()
     ctx.set_option(rt.OPT_COUNT_TESTS, 0)
@@ -241,10 +290,13 @@ def main():
                        "builder": {0: "binned SAH", 1: "Karras LBVH", 2: "PLOC", 3: "binned SAH"}[a.builder] if st["accel"] else "none",
                        "bvh_sah_cost": round(st["bvh_sah_cost"], 2), "bvh_refs": st["bvh_refs"],
                        "leaf_max": st["bvh_leaf_max"], "partition": "%d-row bands round-robin" % a.band_rows if world > 1 else "none",
+                       "frames_in_flight": in_flight,
                        "rays_per_frame": {"primary": rp, "shadow": rs, "reflect": rr}},
             "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
             "roofline": roofline,
         }
+        if frame_latency_ms is not None:
+            out["frame_latency_ms"] = frame_latency_ms      # one frame at a time; ms_per_step is the rate with frames in flight
         if world == 1 and not a.no_extras:
             # the same frames with every launch issued one by one (a frame that changes cannot replay a graph)
             ctx.set_option(rt.OPT_TIMING, 0)
@@ -253,7 +305,13 @@ def main():
                 out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
             ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
             if st["accel"]:
-                out["share_ms"] = share_table(ctx, wl, a.band_rows, torch, dev)
+                out["share_ms"] = share_table([ctx], wl, a.band_rows, torch, dev)
+                more = [make_context() for _ in range(3)]
+                for c in more:
+                    c.set_option(rt.OPT_TIMING, 0)
+                out["share_ms_4_in_flight"] = share_table([ctx] + more, wl, a.band_rows, torch, dev)
+                for c in more:
+                    c.close()
             if a.workload == "sponza":
                 # the second stand-in (irregular triangle sizes, slivers, overlapping cloth) through the same loop
                 wl2 = workloads.atrium2(W=wl.W, H=wl.H, max_depth=wl.max_depth)

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, W, H, band, q):
+def _worker(rank, world, port, W, H, band, q, slots=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -47,9 +47,18 @@ def _worker(rank, world, port, W, H, band, q):
             cap = rt.rows_per_part(H, band, world)
             frame.copy_(torch.from_numpy(deinterleave_numpy(gathered.numpy().reshape(world, cap, W, 3), H, band)))
 
-        pr = PartitionedRenderer(None, W, H, DEPTH, rank, world, band, torch.device("cpu"), render_rows=render_rows,
-                                 deinterleave=deinterleave, dist=dist)
-        out = pr.render()
+        pr = PartitionedRenderer([None] * slots if slots > 1 else None, W, H, DEPTH, rank, world, band, torch.device("cpu"),
+                                 render_rows=render_rows, deinterleave=deinterleave, dist=dist)
+        assert pr.frames_in_flight == slots
+        if slots > 1:
+            # frames in flight: three frames asked for before the first is looked at go to slots 0, 1, 0, each with
+            # buffers of its own; every one is the whole frame
+            frames = [pr.render_async() for _ in range(3)]
+            outs = [f.wait() for f in frames]
+            assert outs[0] is outs[2] and outs[0] is not outs[1]
+            assert torch.equal(outs[0], outs[1])
+            rays[0] = 0                      # the reduction below is about one frame's rays
+        out = pr.render(slot=0) if slots > 1 else pr.render()
         vec = torch.tensor([float(rank + 1), float(rays[0])], dtype=torch.float64)
         mx, sm = reduce_over_ranks(vec, dist)
         if rank == 0:
@@ -64,13 +73,13 @@ def _worker(rank, world, port, W, H, band, q):
 
 # (world, W, H, band): the last two have H that is not a multiple of band * world, and the 4-rank case
 # leaves ranks with different numbers of rows (H = 70, 8-row bands: 9 bands, the last one 6 rows)
-@pytest.mark.parametrize("world,W,H,band", [(2, 96, 64, 8), (2, 96, 70, 8), (4, 64, 70, 8)])
+@pytest.mark.parametrize("world,W,H,band,slots", [(2, 96, 64, 8, 1), (2, 96, 70, 8, 1), (4, 64, 70, 8, 1), (2, 64, 40, 8, 2)])
 @pytest.mark.timeout(300)
-def test_partitioned_renderer_over_gloo_reassembles_the_frame(world, W, H, band):
+def test_partitioned_renderer_over_gloo_reassembles_the_frame(world, W, H, band, slots):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, band, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, band, q, slots)) for r in range(world)]
     for p in procs:
         p.start()
     frame, t_max, rays_sum = q.get(timeout=240)

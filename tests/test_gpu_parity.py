@@ -945,6 +945,44 @@ def test_partitioned_renderer_is_ordered_by_streams_alone():
     assert any(not np.array_equal(got[0], g) for g in got[1:])      # the camera did move
 
 
+def test_frames_in_flight_each_hold_their_own_frame():
+    """Three contexts of one scene as three frame slots, a different camera per slot, seven frames enqueued
+    before the first is waited for: every Frame must hold the picture of ITS slot's camera (slots own their
+    buffers and streams), and the frames of one slot are the same picture every time."""
+    import torch
+    from raytracer_amd.dist import PartitionedRenderer
+    spec = atrium_spec(detail=0.02)
+    W, H, D = 320, 200, 2
+    cams = [rt.Camera(origin=(0.3 * k - 0.3, -1.5 + 0.2 * k, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4) for k in range(3)]
+    ctxs = [rt.Context(0) for _ in cams]
+    try:
+        for c, cam in zip(ctxs, cams):
+            to_product(c, spec)
+            c.set_option(rt.OPT_TIMING, 0)
+            c.set_camera(cam)
+        pr = PartitionedRenderer(ctxs, W, H, D)
+        assert pr.frames_in_flight == 3
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            frames = [pr.render_async() for _ in range(7)]
+            hosts = []
+            for f in frames:
+                h = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
+                h.copy_(f.wait(), non_blocking=True)
+                hosts.append(h)
+            done = torch.cuda.Event()
+            done.record(side)
+        done.synchronize()
+        want = [c.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"] for c in ctxs]
+        for k, h in enumerate(hosts):
+            assert np.array_equal(h.numpy(), want[k % 3]), k
+        assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+        assert np.array_equal(pr.render(slot=1).cpu().numpy(), want[1])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def _wires_and_walls_spec():
     """What whole-triangle boxes handle worst: long thin triangles that cross the scene diagonally, a huge
     two-triangle wall and floor, and small triangles scattered in the space their boxes cover."""

@@ -41,6 +41,35 @@ class _HostStagedGather:
         out.copy_(host_out, non_blocking=False)             # enqueued on the current stream, ahead of the de-interleave
 
 
+def _worker_in_flight(rank, world, port, q):
+    """Two frame slots per rank, a camera per slot, five frames asked for before the first is waited for."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.dist import PartitionedRenderer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctxs = [rt.Context(0) for _ in range(2)]
+        for c, cam in zip(ctxs, _cams()):
+            to_product(c, atrium_spec(detail=0.02))
+            c.set_option(rt.OPT_TIMING, 0)
+            c.set_camera(cam)
+        pr = PartitionedRenderer(ctxs, W, H, D, rank, world, BAND, torch.device("cuda", 0), dist=_HostStagedGather(dist, torch))
+        assert pr.gather_stream is not None and pr.gather_stream is not pr.stream
+        with torch.cuda.stream(torch.cuda.Stream()):
+            frames = [pr.render_async() for _ in range(5)]
+            outs = [f.wait() for f in frames]
+            torch.cuda.current_stream().synchronize()
+            if rank == 0:
+                q.put([outs[0].cpu().numpy().copy(), outs[1].cpu().numpy().copy(), outs[4].cpu().numpy().copy()])
+        dist.barrier()
+        for c in ctxs:
+            c.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -65,6 +94,31 @@ def _worker(rank, world, port, q):
             dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_with_two_frames_in_flight():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        frames = q.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    with rt.Context(0) as c:
+        to_product(c, atrium_spec(detail=0.02))
+        want = []
+        for cam in _cams()[:2]:
+            c.set_camera(cam)
+            want.append(c.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"])
+    assert np.array_equal(frames[0], want[0]) and np.array_equal(frames[1], want[1]) and np.array_equal(frames[2], want[0])
+    assert not np.array_equal(want[0], want[1])
 
 
 @pytest.mark.timeout(300)
