@@ -114,7 +114,7 @@ def share_table(ctxs, wl, band_rows, torch, dev, steps=10):
     return out
 
 
-def measured_traffic(workload, world):
+def measured_traffic(workload, world, resolution):
     """HBM-side bytes per frame of the traversal kernel from the committed counter passes
     (profiles/hbm_traffic.json, written by profiles/hbm_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
     runs).  Counters cannot be read inside this process, so the figure is only reported when the file was
@@ -127,7 +127,7 @@ def measured_traffic(workload, world):
         return None, "none"
     if rec.get("source_hash") != source_hash():
         return None, "profiles/hbm_traffic.json is stale (measured on other kernel sources)"
-    if world != 1 or workload not in rec:
+    if world != 1 or workload not in rec or rec[workload].get("resolution") != list(resolution):
         return None, "profiles/hbm_traffic.json has no entry for this run"
     return rec[workload].get("bytes_per_frame"), "profiles/hbm_traffic.json (" + rec[workload].get("source", "") + ")"
 
@@ -264,7 +264,7 @@ def main():
     # k_trace (LBVH scenes: traversal alone, timed by its own device events) or k_bounce (small scenes)
     kernel_ms = st["ms_traverse"] if st["ms_traverse"] > 0 else st["ms_trace"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    traffic, traffic_source = measured_traffic(a.workload, world)
+    traffic, traffic_source = measured_traffic(a.workload, world, (wl.W, wl.H))
     compulsory = wl.W * wl.H * 3 + wl.n_tris * (48 + 16) + st["bvh_nodes"] * 64
     roofline = {
         "bound": "valu_fp32",
