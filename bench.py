@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--leaf-max", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames a rank keeps in flight (one context and stream each); 0 = 1 on one GPU, 4 when the frame is partitioned")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (slices staged through host memory) is for rehearsing the partitioned job where RCCL cannot run")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (rehearsal of N ranks on a one-GPU box; RCCL refuses that, use --backend gloo)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch of every frame instead of replaying a hipGraph")
     ap.add_argument("--builder", type=int, default=0, help="0 auto (= 3), 1 Karras LBVH, 2 PLOC, 3 binned SAH")
     ap.add_argument("--lib", default="", help="another build of librt_amd.so to load (A/B runs of kernel variants)")
@@ -150,12 +153,19 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist = gather = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            from raytracer_amd.dist import HostStagedGather
+            dist.init_process_group("gloo")
+            gather = HostStagedGather(dist, torch)
 
     kw = {}
     if a.width: kw["W"] = a.width
@@ -186,7 +196,7 @@ def main():
     in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (1 if world == 1 else 4)
     ctxs = [make_context() for _ in range(in_flight)]
     ctx = ctxs[0]
-    pr = PartitionedRenderer(ctxs, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev)
+    pr = PartitionedRenderer(ctxs, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -247,6 +257,8 @@ def main():
     rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
     vec = torch.tensor([dt, float(rays_local), float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"]),
                         st["ms_trace"], st["ms_frame"]], dtype=torch.float64, device=dev)
+    if dist is not None and a.backend != "nccl":
+        vec = vec.cpu()
     mx, sm = reduce_over_ranks(vec, dist)        # times: max over ranks; ray counts: sum over ranks
     dt = float(mx[0])
     rays = float(sm[1]); rp, rs, rr = float(sm[2]), float(sm[3]), float(sm[4])

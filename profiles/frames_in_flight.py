@@ -12,10 +12,15 @@ W, H = 1920, 1080
 wl = workloads.sponza(W=W, H=H)
 rs = rt.band_rowset(H, 16, 0, parts) if parts > 1 else rt.RowSet(0, 1, 1, H)
 chains = []
+dummy = int(os.environ.get("RT_FIF_DUMMY", "0"))        # streams created (and kept) before every chain's stream: shifts which hardware queue it gets
+keep = []
 for k in range(F):
+    keep += [torch.cuda.Stream() for _ in range(dummy)]
     ctx = rt.Context(0)
     wl.load(ctx)
     ctx.set_option(rt.OPT_TIMING, 0)
+    if os.environ.get("RT_NO_GRAPH"):
+        ctx.set_option(rt.OPT_GRAPH, 0)
     chains.append((ctx, torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), torch.cuda.Stream()))
 for it in range(frames + 2 * F):
     if it == 2 * F:

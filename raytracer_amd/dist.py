@@ -45,6 +45,22 @@ def reduce_over_ranks(vec, dist=None):
     return mx, sm
 
 
+class HostStagedGather:
+    """all_gather_into_tensor for device tensors over a process group that only moves host memory (gloo): the slice
+    goes through the host, ordered on the current stream.  For rehearsing the partitioned job where RCCL cannot run
+    (several ranks on one GPU); pass it as `dist` to PartitionedRenderer."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def all_gather_into_tensor(self, out, inp):
+        torch = self.torch
+        torch.cuda.current_stream().synchronize()           # the slice is complete before it leaves the device
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host_out, inp.cpu())
+        out.copy_(host_out, non_blocking=False)             # enqueued on the current stream, ahead of the de-interleave
+
+
 class Frame:
     """One enqueued frame.  `wait()` orders the caller's current stream behind it and returns the tensor
     (the full frame on rank 0, this rank's slice elsewhere)."""

@@ -27,18 +27,7 @@ def _cams():
     return [rt.Camera(origin=(0.3 * k - 0.3, -1.5, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4) for k in range(3)]
 
 
-class _HostStagedGather:
-    """all_gather_into_tensor over gloo for device tensors: through host memory, ordered on the current stream."""
-
-    def __init__(self, dist, torch):
-        self.dist, self.torch = dist, torch
-
-    def all_gather_into_tensor(self, out, inp):
-        torch = self.torch
-        torch.cuda.current_stream().synchronize()           # the slice is complete before it leaves the device
-        host_out = torch.empty(out.shape, dtype=out.dtype)
-        self.dist.all_gather_into_tensor(host_out, inp.cpu())
-        out.copy_(host_out, non_blocking=False)             # enqueued on the current stream, ahead of the de-interleave
+from raytracer_amd.dist import HostStagedGather as _HostStagedGather
 
 
 def _worker_in_flight(rank, world, port, q):
@@ -143,3 +132,30 @@ def test_two_ranks_on_one_gpu_reassemble_the_frame():
             want = c.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"]
             assert np.array_equal(got, want)
     assert not np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.timeout(400)
+def test_bench_partitioned_job_two_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), rehearsed on one GPU:
+    the gloo backend with host-staged slices stands in for RCCL, everything else is the job's own code — band partition,
+    four frames in flight per rank, the max/sum reduction over ranks, the one JSON line from rank 0.  The rays of the two
+    halves must add up to the frame's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--width", "640", "--height", "360"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=300, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--share-device"] + common, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                         # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 4
+    assert d["config"]["rays_per_frame"] == single["config"]["rays_per_frame"]
+    assert d["value"] > 0 and d["frame_latency_ms"] >= d["ms_per_step"] * 0.5
