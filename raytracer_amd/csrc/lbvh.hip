@@ -1166,10 +1166,12 @@ __device__ __forceinline__ float half_area3(const float *l, const float *h)
 }
 
 // ord[p] = p, every position in segment 0 (or in none when the whole input is one small segment); centroid bounds of
-// the root: per-wave reduction, six atomics per wave.
+// the root: every thread folds many references, a wave reduces by shuffles, the block by LDS, one lane per block issues
+// the six atomics (they land in one cache line, where atomics retire at about 90 per microsecond).
 __global__ __launch_bounds__(256) void k_sah_init(const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi, int n, int root_slot,
                                                   unsigned int *ord, int *seg_of, unsigned int *cb)
 {
+    __shared__ float s_lo[4][3], s_hi[4][3];
     float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         ord[p] = (unsigned)p;
@@ -1183,11 +1185,17 @@ __global__ __launch_bounds__(256) void k_sah_init(const float4 *__restrict__ ref
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&cb[k], float_to_ordered(lo[k]));
-            atomicMax(&cb[3 + k], float_to_ordered(hi[k]));
-        }
+        for (int k = 0; k < 3; k++) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = s_lo[0][k], b = s_hi[0][k];
+        for (int w = 1; w < 4; w++) { a = fminf(a, s_lo[w][k]); b = fmaxf(b, s_hi[w][k]); }
+        atomicMin(&cb[k], float_to_ordered(a));
+        atomicMax(&cb[3 + k], float_to_ordered(b));
+    }
 }
 
 __global__ void k_sah_clear(SahBin *bins, int count)
@@ -1249,35 +1257,57 @@ __device__ __forceinline__ int sah_local_segment(const int *__restrict__ seg_of,
 // of the build).
 __global__ __launch_bounds__(256) void k_sah_bin(const unsigned int *__restrict__ ord, const int *__restrict__ seg_of, int n,
                                                  const float4 *__restrict__ ref_lo, const float4 *__restrict__ ref_hi,
-                                                 const unsigned int *__restrict__ cb, int n_act, SahBin *bins)
+                                                 const unsigned int *__restrict__ cb, int n_act, int chunks, SahBin *bins)
 {
     __shared__ SahBin s_bin[SAH_BLOCK_SEGS * 3 * SAH_BINS];
     __shared__ int s_wave[4], s_slot[SAH_BLOCK_SEGS];
-    for (int e = threadIdx.x; e < SAH_BLOCK_SEGS * 3 * SAH_BINS; e += 256) {
-        SahBin b;
-        b.count = 0;
-        for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
-        s_bin[e] = b;
-    }
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    int s, n_local;
-    const int local = sah_local_segment(seg_of, p, n, n_act, s_wave, s_slot, s, n_local);     // its barriers also order the clearing above
-    if (local >= 0) {
-        const unsigned int r = ord[p];
-        const float4 l = ref_lo[r], h = ref_hi[r];
-        const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
-        for (int a = 0; a < 3; a++) {
-            const int b = sah_bin_of(c[a], ordered_to_float(cb[6 * s + a]), ordered_to_float(cb[6 * s + 3 + a]), SAH_BINS);
-            sah_bin_add(local < SAH_BLOCK_SEGS ? &s_bin[(local * 3 + a) * SAH_BINS + b] : &bins[((size_t)s * 3 + a) * SAH_BINS + b], l, h);
+    // A block takes `chunks` runs of 256 positions.  While they all lie in one segment (the first rounds of a large
+    // input) it collects them all before it touches the global bins: fewer adds to the few cache lines every block wants.
+    const int first = blockIdx.x * chunks * 256;
+    if (first >= n) return;
+    const int last = min(first + chunks * 256, n) - 1;
+    const int s_first = seg_of[first];
+    const bool one_segment = chunks > 1 && s_first >= 0 && s_first < n_act && s_first == seg_of[last];
+    for (int chunk = 0; chunk < chunks; chunk++) {
+        const int p = first + chunk * 256 + threadIdx.x;
+        if (first + chunk * 256 >= n) break;
+        if (!one_segment || chunk == 0) {
+            __syncthreads();                                      // the flush of the chunk before has read s_bin
+            for (int e = threadIdx.x; e < SAH_BLOCK_SEGS * 3 * SAH_BINS; e += 256) {
+                SahBin b;
+                b.count = 0;
+                for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
+                s_bin[e] = b;
+            }
         }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < n_local * 3 * SAH_BINS; e += 256) {
-        const SahBin b = s_bin[e];
-        if (!b.count) continue;
-        SahBin *g = &bins[(size_t)s_slot[e / (3 * SAH_BINS)] * 3 * SAH_BINS + e % (3 * SAH_BINS)];
-        atomicAdd(&g->count, b.count);
-        for (int k = 0; k < 3; k++) { atomicMin(&g->lo[k], b.lo[k]); atomicMax(&g->hi[k], b.hi[k]); }
+        int s, n_local, local;
+        if (one_segment) {
+            if (chunk == 0) {
+                if (threadIdx.x == 0) s_slot[0] = s_first;
+                __syncthreads();
+            }
+            s = s_first; n_local = 1; local = p < n ? 0 : -1;
+        } else {
+            local = sah_local_segment(seg_of, p, n, n_act, s_wave, s_slot, s, n_local);     // its barriers also order the clearing above
+        }
+        if (local >= 0) {
+            const unsigned int r = ord[p];
+            const float4 l = ref_lo[r], h = ref_hi[r];
+            const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
+            for (int a = 0; a < 3; a++) {
+                const int b = sah_bin_of(c[a], ordered_to_float(cb[6 * s + a]), ordered_to_float(cb[6 * s + 3 + a]), SAH_BINS);
+                sah_bin_add(local < SAH_BLOCK_SEGS ? &s_bin[(local * 3 + a) * SAH_BINS + b] : &bins[((size_t)s * 3 + a) * SAH_BINS + b], l, h);
+            }
+        }
+        if (one_segment && chunk + 1 < chunks && first + (chunk + 1) * 256 < n) continue;       // keep collecting
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_local * 3 * SAH_BINS; e += 256) {
+            const SahBin b = s_bin[e];
+            if (!b.count) continue;
+            SahBin *g = &bins[(size_t)s_slot[e / (3 * SAH_BINS)] * 3 * SAH_BINS + e % (3 * SAH_BINS)];
+            atomicAdd(&g->count, b.count);
+            for (int k = 0; k < 3; k++) { atomicMin(&g->lo[k], b.lo[k]); atomicMax(&g->hi[k], b.hi[k]); }
+        }
     }
 }
 
@@ -1718,16 +1748,18 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
         if (!n_act) {
             RT_HIP_CHECK(hipMemcpyAsync(sc.p + 2, &n_small, sizeof(int), hipMemcpyHostToDevice, stream), err);
         }
-        hipLaunchKernelGGL(k_sah_init, dim3(G < 1024 ? G : 1024), dim3(256), 0, stream, ref_lo.p, ref_hi.p, n, n_act ? 0 : -1, vals[0].p, seg_of[0].p,
+        hipLaunchKernelGGL(k_sah_init, dim3(G < 512 ? G : 512), dim3(256), 0, stream, ref_lo.p, ref_hi.p, n, n_act ? 0 : -1, vals[0].p, seg_of[0].p,
                            cb[0].p);
         int a_cur = 0;
+        const int bin_chunks = std::max(1, std::min(8, n >> 18));        // runs of 256 positions per binning block
         for (int round = 0; n_act > 0; round++) {
             if (round > 64) {
                 if (err) *err = "SAH builder: the rounds do not end";
                 return RT_E_DEVICE;
             }
             hipLaunchKernelGGL(k_sah_clear, dim3(blocks_for(n_act * 3 * SAH_BINS, B)), dim3(B), 0, stream, bins.p, n_act * 3 * SAH_BINS);
-            hipLaunchKernelGGL(k_sah_bin, dim3(G), dim3(256), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p, cb[a_cur].p, n_act, bins.p);
+            hipLaunchKernelGGL(k_sah_bin, dim3(blocks_for(n, 256 * bin_chunks)), dim3(256), 0, stream, vals[cur].p, seg_of[a_cur].p, n, ref_lo.p, ref_hi.p,
+                               cb[a_cur].p, n_act, bin_chunks, bins.p);
             RT_HIP_CHECK(hipMemsetAsync(sc.p + 1, 0, sizeof(int), stream), err);
             hipLaunchKernelGGL(k_sah_split, dim3(n_act), dim3(64), 0, stream, act[a_cur].p, n_act, bins.p, n, children.p, range.p,
                                parent.p, sc.p, small.p, act[a_cur ^ 1].p, cap, cb[a_cur ^ 1].p, cut.p);
