@@ -1133,8 +1133,8 @@ namespace {
 // ------------------------------------------------------------------ top-down binned SAH (builder 3)
 // The tree a surface-area-heuristic sweep gives, built on the device.  Every open node owns a contiguous
 // range ("segment") of one order array.  A segment longer than SAH_SMALL references is split by the whole grid, one
-// tree level per round: every reference drops its box into one of SAH_BINS bins per axis (atomics, collected in LDS
-// first when a block lies inside one segment), one thread per segment sweeps the 3 x (SAH_BINS-1) planes for the
+// tree level per round: every reference drops its box into one of SAH_BINS bins per axis (atomics, collected per block
+// in LDS for every segment the block meets), one wave per segment sweeps the 3 x (SAH_BINS-1) planes for the
 // cheapest cut, a scan of the "goes left" flags places every reference (a stable partition), and the children's
 // centroid bounds are gathered on the way.  A segment of at most SAH_SMALL references is finished by ONE wave, down to
 // single references, out of LDS.  Node ids: a node that cuts its range after position g ("gamma") is inner node g --
