@@ -149,7 +149,7 @@ struct FrameWorkspace {
     size_t pixels_cap = 0;
     int levels_cap = 0;
     // wavefront pipeline (LBVH scenes)
-    float4 *sq_o = nullptr, *sq_d = nullptr;   // [seg_cap][slots_cap] shadow rays, one segment per light of a chunk
+    float4 *sq_o = nullptr;   // [seg_cap][slots_cap] shadow rays (hit point, pixel), one segment per light of a chunk
     unsigned int *rq_counts[2] = { nullptr, nullptr };   // [regions] rays per region of each ray queue
     unsigned int *fq_counts[2] = { nullptr, nullptr };   // fused kernel: rays per 64-slot batch of each ray queue
     unsigned int *sq_counts = nullptr;         // [seg_cap][regions] shadow rays per segment and region

@@ -166,7 +166,7 @@ void free_triangles(rt_ctx *c)
 void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
-                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1],
+                     ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.rq_counts[0], ws.rq_counts[1],
                      ws.sq_counts, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -229,17 +229,16 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
         const int cus = device_num_cus(&err);
         if (cus <= 0) return fail(RT_E_DEVICE, err);
         if (qslots > ws.slots_cap || n_chunks > ws.chunks_cap || segs > ws.seg_cap) {
-            void *old[] = { ws.sq_o, ws.sq_d, ws.rq_counts[0], ws.rq_counts[1], ws.sq_counts };
+            void *old[] = { ws.sq_o, ws.rq_counts[0], ws.rq_counts[1], ws.sq_counts };
             for (void *p : old)
                 if (p) (void)hipFree(p);
-            ws.sq_o = ws.sq_d = nullptr;
+            ws.sq_o = nullptr;
             ws.rq_counts[0] = ws.rq_counts[1] = ws.sq_counts = nullptr;
             const size_t sc = qslots > ws.slots_cap ? qslots : ws.slots_cap;
             const int cc = n_chunks > ws.chunks_cap ? n_chunks : ws.chunks_cap, gc = segs > ws.seg_cap ? segs : ws.seg_cap;
             const size_t regions = wavefront_regions(sc);
             ws.slots_cap = 0; ws.chunks_cap = 0; ws.seg_cap = 0;
             hipError_t e = hipMalloc((void **)&ws.sq_o, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
-            if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_d, sizeof(float4) * sc * (size_t)(gc ? gc : 1));
             if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[0], sizeof(unsigned int) * regions);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.rq_counts[1], sizeof(unsigned int) * regions);
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_counts, sizeof(unsigned int) * regions * (size_t)(gc ? gc : 1));
@@ -397,7 +396,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         key.fp = fp; key.sc = sc; key.cam = c->cam;
         key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
         void *wsp[16] = { c->ws.records, c->ws.queue_o[0], c->ws.queue_o[1], c->ws.queue_d[0], c->ws.queue_d[1], c->ws.counters,
-                          c->ws.p_hits, c->ws.p_occ, c->ws.sq_o, c->ws.sq_d, c->ws.trace_cursors, c->ws.overflow,
+                          c->ws.p_hits, c->ws.p_occ, c->ws.sq_o, nullptr, c->ws.trace_cursors, c->ws.overflow,
                           c->ws.rq_counts[0], c->ws.rq_counts[1], c->ws.sq_counts, c->ws.hit_t };
         memcpy(key.ws, wsp, sizeof wsp);
         key.version = c->state_version;

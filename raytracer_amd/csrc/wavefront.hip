@@ -84,7 +84,7 @@ struct TraceArgs {
     DevCamera cam;
     int W, n_rows;
     rt_rowset rows;
-    const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit and mixed: shadow queue (segment-major)
+    const float4 *q_o, *q_d;        // closest, level > 0: ray queue; any-hit and mixed: q_o = shadow queue (segment-major: hit point, pixel)
     const float4 *q2_o, *q2_d;      // mixed: the next level's ray queue, traced for the nearest hit
     float2 *hits;                   // nearest hit: (t, id bits) per PIXEL, the plane of the level being traced
     unsigned int *occ;              // any-hit: occ[pixel] |= 1 << bit, the plane of (level, light chunk)
@@ -94,6 +94,7 @@ struct TraceArgs {
     unsigned int n_slots;           // level 0: slot count known on the host
     int n_segments, n_regions;
     unsigned int seg_stride;        // queue entries between segments
+    int light0;                     // any-hit and mixed: the light of segment 0 (index into sc.lights)
     int *overflow;                  // [WF_OVF][total_lanes]
     unsigned int total_lanes;
     FrameCounters *counters;
@@ -212,10 +213,15 @@ void k_trace(TraceArgs A)
                 const bool unit_any = MODE == 1 || (MODE == 2 && seg < A.n_segments);     // wave-uniform
                 if (unit_any) {
                     const size_t q = (size_t)RTG((size_t)seg * A.seg_stride + my, A.q_cap);
-                    const float4 qo = A.q_o[q], qd = A.q_d[q];
-                    o = f3(qo); d = f3(qd);
+                    const float4 qo = A.q_o[q];
                     slot = (unsigned)__float_as_int(qo.w);
-                    bit = __float_as_int(qd.w);
+                    // A queued shadow ray is its hit point and pixel (16 bytes, half of what the ray itself would take through
+                    // the queue); the ray is formed here exactly as k_shadow_gen and k_shade_all form it (main.cpp:178-179).
+                    const DevAnalytic lt_ = sc.analytic[sc.lights[A.light0 + seg]];
+                    const F3 pos = f3(qo);
+                    const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));
+                    o = add(pos, muls(L, 0.01f)); d = L;
+                    bit = seg;
                 } else if (PRIMARY) {
                     const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, my);
                     o = pr.o; d = pr.d; live = pr.live;
@@ -388,7 +394,7 @@ struct ShadeArgs {
     unsigned int slots_cap;
     // k_shadow_gen
     int chunk;
-    float4 *sq_o, *sq_d;              // [segment][slots_cap]
+    float4 *sq_o;                     // [segment][slots_cap] (hit point, pixel)
     unsigned int *sq_counts;          // [segment][region]
     float4 *nq_o, *nq_d;              // next level's rays
     unsigned int *out_counts;         // next level's rays per region
@@ -500,8 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             const unsigned int rank = block_rank(want, s_cnt, total);
             if (want) {
                 const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
-                A.sq_o[q] = make_float4(so.x, so.y, so.z, __int_as_float(r.pixel));
-                A.sq_d[q] = make_float4(L.x, L.y, L.z, __int_as_float(li - l0));
+                A.sq_o[q] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));      // the traversal forms L and the origin again
             }
             if (threadIdx.x == 0) A.sq_counts[(size_t)(li - l0) * A.n_regions + region] = total;
         }
@@ -565,6 +570,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     t.n_pix = (unsigned)n_pixels;
     t.n_wnodes = (unsigned)(WIDE_TOP_NODES + (scene.n_refs > 1 ? scene.n_refs - 1 : 1));
     t.q_cap = t.q2_cap = (unsigned long long)ws.pixels_cap;
+    t.light0 = 0;
 
     ShadeArgs s;
     s.sc = scene; s.cam = cam; s.W = fp.W; s.n_rows = n_rows; s.n_pixels = n_pixels; s.rows = fp.rows;
@@ -572,7 +578,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     s.n_slots = n_slots; s.n_regions = n_regions;
     s.hits = ws.p_hits;
     s.occ = ws.p_occ; s.slots_cap = (unsigned)ws.slots_cap;
-    s.sq_o = ws.sq_o; s.sq_d = ws.sq_d; s.sq_counts = ws.sq_counts;
+    s.sq_o = ws.sq_o; s.sq_counts = ws.sq_counts;
     s.counters = ws.counters;
     // hit and occlusion planes are indexed [level][pixel] and [level][chunk][pixel]: k_shade_all reads
     // every level of a pixel at the end of the frame
@@ -635,11 +641,12 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
             t.occ = nullptr;
             t.n_segments = 1; t.seg_stride = 0;
         } else {
-            t.q_o = ws.sq_o; t.q_d = ws.sq_d;
+            t.q_o = ws.sq_o; t.q_d = nullptr;
             t.q_cap = (unsigned long long)ws.slots_cap * (unsigned long long)(ws.seg_cap ? ws.seg_cap : 1);
             t.counts = ws.sq_counts;
             t.occ = occ_of(level, chunk);
             t.n_segments = (chunk == n_chunks - 1) ? scene.n_lights - 32 * chunk : 32;
+            t.light0 = 32 * chunk;
             t.seg_stride = (unsigned)ws.slots_cap;
             t.q2_o = ws.queue_o[(level + 1) & 1]; t.q2_d = ws.queue_d[(level + 1) & 1];
             t.counts2 = ws.rq_counts[(level + 1) & 1];
