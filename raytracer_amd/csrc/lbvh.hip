@@ -9,14 +9,18 @@
 //
 // Pipeline (all kernels, no host geometry work):
 //   k_tri_setup_*   Triangle constructor: v1, e1, e2, N
-//   k_bounds        scene bounds of the triangle centroids (wave + block reduce, ordered-int atomics)
-//   k_morton        63-bit Morton code per centroid
-//   radix sort      8 passes x 8 bits, stable; one wave per 1024-key tile, ballot-based ranking
-//   k_karras        Karras 2012 hierarchy from the sorted codes
+//   k_bounds        scene bounds (wave + block reduce, ordered-int atomics)
+//   k_split_*       triangle references: a large triangle is cut by a grid into references with clipped boxes
+//   binary tree over the references, one of
+//     k_sah_*       top-down binned surface-area-heuristic sweep (the default), checked by k_tree_check
+//     k_ploc_*      agglomeration over the Morton order (k_morton + 8-pass radix sort first)
+//     k_karras      Karras 2012 radix tree from the sorted Morton codes
 //   k_node_depth    depth of every internal node (parent walk)
 //   k_refit_level   bottom-up box union, one launch per depth (no in-kernel hand-offs)
-//   k_emit          64-byte traversal nodes with both children's padded boxes; subtrees
-//                   of <= leaf_max triangles collapse into one leaf
+//   k_emit          64-byte float nodes with both children's padded boxes (fused pipeline); subtrees
+//                   of <= leaf_max references collapse into one leaf
+//   k_wide_*, k_emit_wide   the tree collapsed to four children per node on a 15-bit lattice (staged pipeline)
+//   k_gather_tris   triangles in leaf order
 #include "rt_internal.h"
 
 #include <float.h>
