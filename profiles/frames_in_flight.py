@@ -21,7 +21,8 @@ for k in range(F):
     ctx.set_option(rt.OPT_TIMING, 0)
     if os.environ.get("RT_NO_GRAPH"):
         ctx.set_option(rt.OPT_GRAPH, 0)
-    chains.append((ctx, torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), torch.cuda.Stream()))
+    prio = [int(x) for x in os.environ.get("RT_FIF_PRIO", "0").split(",")]
+    chains.append((ctx, torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"), torch.cuda.Stream(priority=prio[k % len(prio)])))
 for it in range(frames + 2 * F):
     if it == 2 * F:
         torch.cuda.synchronize(); t0 = time.perf_counter()
