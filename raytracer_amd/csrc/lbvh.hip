@@ -88,14 +88,31 @@ __global__ void k_tri_setup_indexed(const float *__restrict__ verts, int n_verts
 // ------------------------------------------------------------------ bounds + Morton codes
 // The box of a triangle is the box of the three points the intersector actually
 // sees: v1, v1+e1, v1+e2.
+// A triangle with a NaN or an infinity among the values the intersector reads (v1, e1, e2) can never be hit (its
+// Moller-Trumbore t comes out as NaN or 0, never > 1e-4), but it would poison the scene bounds, the Morton codes and
+// every box union above it.  For the builder it is a point at the origin; the intersector still sees the caller's values.
+__device__ inline bool tri_corners(const float4 *__restrict__ tri_mt, int i, float v[3][3])
+{
+    const float4 a = tri_mt[3 * (size_t)i], e1 = tri_mt[3 * (size_t)i + 1], e2 = tri_mt[3 * (size_t)i + 2];
+    v[0][0] = a.x; v[0][1] = a.y; v[0][2] = a.z;
+    v[1][0] = a.x + e1.x; v[1][1] = a.y + e1.y; v[1][2] = a.z + e1.z;
+    v[2][0] = a.x + e2.x; v[2][1] = a.y + e2.y; v[2][2] = a.z + e2.z;
+    const float w[9] = { a.x, a.y, a.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };
+    bool finite = true;
+    for (int k = 0; k < 9; k++) finite = finite && fabsf(w[k]) <= FLT_MAX;
+    if (!finite)
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 3; k++) v[c][k] = 0.f;
+    return finite;
+}
+
 __device__ inline void tri_box(const float4 *__restrict__ tri_mt, int i, float lo[3], float hi[3])
 {
-    float4 a = tri_mt[3 * (size_t)i], e1 = tri_mt[3 * (size_t)i + 1], e2 = tri_mt[3 * (size_t)i + 2];
-    float p[3] = { a.x, a.y, a.z }, q[3] = { a.x + e1.x, a.y + e1.y, a.z + e1.z },
-          r[3] = { a.x + e2.x, a.y + e2.y, a.z + e2.z };
+    float v[3][3];
+    (void)tri_corners(tri_mt, i, v);
     for (int k = 0; k < 3; k++) {
-        lo[k] = fminf(p[k], fminf(q[k], r[k]));
-        hi[k] = fmaxf(p[k], fmaxf(q[k], r[k]));
+        lo[k] = fminf(v[0][k], fminf(v[1][k], v[2][k]));
+        hi[k] = fmaxf(v[0][k], fmaxf(v[1][k], v[2][k]));
     }
 }
 
@@ -153,10 +170,7 @@ struct SplitGrid {
 __device__ inline SplitGrid split_grid(const float4 *__restrict__ tri_mt, int i, const unsigned int *__restrict__ bounds, int max_cells)
 {
     SplitGrid g;
-    const float4 a = tri_mt[3 * (size_t)i], e1 = tri_mt[3 * (size_t)i + 1], e2 = tri_mt[3 * (size_t)i + 2];
-    g.v[0][0] = a.x; g.v[0][1] = a.y; g.v[0][2] = a.z;
-    g.v[1][0] = a.x + e1.x; g.v[1][1] = a.y + e1.y; g.v[1][2] = a.z + e1.z;
-    g.v[2][0] = a.x + e2.x; g.v[2][1] = a.y + e2.y; g.v[2][2] = a.z + e2.z;
+    (void)tri_corners(tri_mt, i, g.v);
     float ext = 0.f;
     for (int k = 0; k < 3; k++) ext = fmaxf(ext, ordered_to_float(bounds[3 + k]) - ordered_to_float(bounds[k]));
     const float h = ext / SPLIT_RES;

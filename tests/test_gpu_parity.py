@@ -374,6 +374,37 @@ def test_sah_builder_on_every_path_equals_linear_scan(kind):
         assert rays(st) == rays(base["stats"])
 
 
+@pytest.mark.parametrize("builder", [rt.BUILDER_SAH, rt.BUILDER_PLOC, rt.BUILDER_LBVH])
+def test_triangles_with_nan_or_infinite_vertices_never_hit_and_never_break_the_build(builder):
+    """A NaN or an infinity in a vertex makes the reference's Moller-Trumbore test fail for every ray (t comes out NaN or
+    0, main.cpp:127-128); such triangles must not poison the scene bounds either.  3000 triangles, five of them broken
+    (and one duplicated): every builder's frame equals the linear scan bit for bit, and no broken triangle is ever hit."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    c = rng.uniform(-4, 4, (n, 3)); c[:, 2] += 5
+    tri = (c[:, None, :] + rng.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
+    broken = [5, 17, 100, 200, 2999]
+    tri[5, 1, 0] = np.nan; tri[17, :, :] = np.nan; tri[100, 2, 1] = np.inf; tri[200, 0, 2] = -np.inf; tri[2999, 1, :] = np.inf
+    tri[300] = tri[301]
+    verts, idx = tri.reshape(-1, 3), np.arange(n * 3, dtype=np.int32)
+    W, H = 96, 64
+    outs = []
+    for accel in (rt.ACCEL_LINEAR, rt.ACCEL_LBVH):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, accel)
+            ctx.set_option(rt.OPT_BUILDER, builder)
+            ctx.set_analytic([rt.Sphere((2.0, 5.0, 1.0), 0.1, None, True)])
+            ctx.set_mesh(verts, idx, rt.Material(reflect=0.3))
+            ctx.set_camera(rt.Camera(pitch=8.0 / W))
+            outs.append(ctx.render_frame(W, H, max_depth=2, want=("hit_id", "rgb32")))
+            st = ctx.stats()
+    assert st["accel"] == 1 and st["bvh_depth"] <= 64
+    assert np.array_equal(outs[0]["hit_id"], outs[1]["hit_id"])
+    assert np.array_equal(outs[0]["rgb32"].view(np.uint32), outs[1]["rgb32"].view(np.uint32))
+    assert not np.isin(outs[0]["hit_id"], [1 + b for b in broken]).any()       # ids: the light sphere is 0, triangle k is 1 + k
+    assert (outs[0]["hit_id"] > 0).sum() > 500
+
+
 # ------------------------------------------------------------------ moving geometry (refit)
 def _moved(verts, step):
     """A deformation that changes the scene bounds: a swell along x and a shear in y, growing with step."""
