@@ -217,7 +217,7 @@ void k_trace(TraceArgs A)
                     slot = (unsigned)__float_as_int(qo.w);
                     // A queued shadow ray is its hit point and pixel (16 bytes, half of what the ray itself would take through
                     // the queue); the ray is formed here exactly as k_shadow_gen and k_shade_all form it (main.cpp:178-179).
-                    const DevAnalytic lt_ = sc.analytic[sc.lights[A.light0 + seg]];
+                    const DevAnalytic lt_ = sc.analytic[RTG(sc.lights[RTG(A.light0 + seg, sc.n_lights)], sc.n_analytic)];
                     const F3 pos = f3(qo);
                     const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));
                     o = add(pos, muls(L, 0.01f)); d = L;
