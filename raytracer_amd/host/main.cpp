@@ -32,6 +32,7 @@ struct Config {
     std::string out = "frame.ppm", pfm, ids, obj, exr;
     bool raw_order = false, mirror = true, floor = true, relaxed = false, smooth = false;
     int frames = 1;
+    int builder = 0, leaf_max = 0;                           // hierarchy options (0: the library's defaults)
     float mesh_reflect = 0.0f;                               // main.cpp:34: meshes do not reflect
     float wobble = 0.0f;
     int device = 0;
@@ -179,6 +180,9 @@ void setup()
         return;
     }
 
+    if (cfg.builder && !check(rt_set_option(ctx, RT_OPT_BUILDER, cfg.builder), "rt_set_option(builder)")) return;
+    if (cfg.leaf_max && !check(rt_set_option(ctx, RT_OPT_LEAF_MAX, cfg.leaf_max), "rt_set_option(leaf max)")) return;
+
     // the stock scene, main.cpp:240-255
     std::vector<rt_analytic> scene;
     if (cfg.mirror) scene.push_back(sphere(0.0f, 0.0f, 0.0f, 2.5f, material(1.0f, 0.0f, 1.0f, 1.0f, 1.0f, 1.0f), false));
@@ -311,6 +315,8 @@ int main(int argc, char *argv[])
         else if (a == "--exr") cfg.exr = val();
         else if (a == "--frames") cfg.frames = atoi(val());
         else if (a == "--wobble") cfg.wobble = (float)atof(val());
+        else if (a == "--builder") cfg.builder = atoi(val());
+        else if (a == "--leaf-max") cfg.leaf_max = atoi(val());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     glwt_headless_frames = cfg.frames > 1 ? cfg.frames : 1;
