@@ -297,3 +297,29 @@ def test_every_device_derived_index_of_the_queue_kernels_is_guarded():
     # node, triangle and spill-slot references
     assert "RTG(node, A.n_wnodes)" in body and "RTG(tri_i, sc.n_refs)" in body and body.count("RTG(sp - WF_LDS_STACK, WF_OVF)") == 2
     assert os.path.exists(os.path.join(ROOT, "raytracer_amd", "variants", "guard.so")), "build() must also produce the guarded variant"
+
+
+def test_bench_reports_counter_traffic_only_for_the_sources_and_frame_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed counter run; it is only valid for the kernel sources, workload and
+    resolution of that run.  bench.measured_traffic must say null (with the reason) for anything else."""
+    import importlib.util
+    import json
+    from raytracer_amd.build import source_hash
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    (tmp_path / "profiles").mkdir()
+    rec = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "bytes_per_frame": 123.0, "source": "x.txt"}}
+    (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_traffic("sponza", 1, (1920, 1080))[0] == 123.0
+    assert bench.measured_traffic("sponza", 1, (3840, 2160))[0] is None        # another frame size
+    assert bench.measured_traffic("soup", 1, (1920, 1080))[0] is None          # another workload
+    assert bench.measured_traffic("sponza", 2, (1920, 1080))[0] is None        # a partitioned run
+    rec["source_hash"] = "0" * 16
+    (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
+    got, why = bench.measured_traffic("sponza", 1, (1920, 1080))
+    assert got is None and "stale" in why
+    # the committed file itself is either valid for the committed sources or reported as stale, never silently wrong
+    committed = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert "source_hash" in committed and "sponza" in committed and committed["sponza"]["resolution"] == [1920, 1080]
