@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames a rank keeps in flight (one context and stream each); 0 = 4 when the frame is partitioned and a rank's share is at most 1.5 M pixels, else 1")
+                    help="frames a rank keeps in flight (one frame slot and stream each); 0 = 4 when the frame is partitioned and a rank's share is at most 1.5 M pixels, else 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (slices staged through host memory) is for rehearsing the partitioned job where RCCL cannot run")
     ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (rehearsal of N ranks on a one-GPU box; RCCL refuses that, use --backend gloo)")
@@ -97,23 +97,24 @@ def timed_frames(render, sync, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def share_table(ctxs, wl, band_rows, torch, dev, steps=10):
+def share_table(ctx, n_slots, wl, band_rows, torch, dev, steps=10):
     """One rank's share of the frame, measured on this GPU: part 0 of 1, 2, 4 and 8 parts (16-row bands
-    round-robin), graph replay, RGB8 only, ms per frame, with len(ctxs) frames in flight (one context, stream and
-    buffer each, frames round-robin).  What strong scaling can reach before the gather."""
+    round-robin), graph replay, RGB8 only, ms per frame, with n_slots frames in flight (one frame slot of the context,
+    one stream and one buffer each, frames round-robin).  What strong scaling can reach before the gather."""
     import raytracer_amd as rt
     out = {}
-    slots = [(c, torch.zeros((wl.H, wl.W, 3), dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev)) for c in ctxs]
+    slots = [(torch.zeros((wl.H, wl.W, 3), dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev)) for _ in range(n_slots)]
     for parts in (1, 2, 4, 8):
         rs = rt.band_rowset(wl.H, band_rows, 0, parts) if parts > 1 else rt.RowSet(0, 1, 1, wl.H)
         turn = [0]
 
         def render():
-            c, buf, stream = slots[turn[0] % len(slots)]
+            k = turn[0] % n_slots
             turn[0] += 1
-            c.render_rows_device(wl.W, wl.H, rs, wl.max_depth, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+            buf, stream = slots[k]
+            ctx.render_rows_device(wl.W, wl.H, rs, wl.max_depth, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream, slot=k)
 
-        out[str(parts)] = timed_frames(render, torch.cuda.synchronize, steps * len(slots), 3 * len(slots))
+        out[str(parts)] = timed_frames(render, torch.cuda.synchronize, steps * n_slots, 3 * n_slots)
     return out
 
 
@@ -191,15 +192,14 @@ def main():
         return c
 
     # One rank's share of a partitioned frame leaves most of the GPU idle (fewer rays than lanes, six dependent launches
-    # each as long as its longest rays), so a partitioned job keeps several frames in flight: one context, stream and
-    # buffer set per frame slot.  On one GPU the whole frame fills the chip and one slot is enough.
+    # each as long as its longest rays), so a partitioned job keeps several frames in flight: one frame slot of the
+    # context, one stream and one buffer set each.  On one GPU the whole frame fills the chip and one slot is enough.
     # (Measured on one GPU, share of 1080p: whole frame +1.6 %, half 1.14x, quarter 1.43x, eighth 1.9x with four slots: a share
     # of more than ~1.5 M pixels fills the chip by itself and is not worth three more scene copies.)
     share_pixels = wl.W * wl.H // world
     in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (4 if world > 1 and share_pixels <= 1_500_000 else 1)
-    ctxs = [make_context() for _ in range(in_flight)]
-    ctx = ctxs[0]
-    pr = PartitionedRenderer(ctxs, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather)
+    ctx = make_context()
+    pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather, frames_in_flight=in_flight)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -209,8 +209,7 @@ def main():
 
     # the timed loop runs without per-launch device events, so that an unchanged frame replays as one
     # hipGraph; kernel times come from one more frame with the events on, outside the timed region
-    for c in ctxs:
-        c.set_option(rt.OPT_TIMING, 0)
+    ctx.set_option(rt.OPT_TIMING, 0)
     frame_latency_ms = None
     if in_flight == 1:
         # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
@@ -320,13 +319,8 @@ def main():
                 out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
             ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
             if st["accel"]:
-                out["share_ms"] = share_table([ctx], wl, a.band_rows, torch, dev)
-                more = [make_context() for _ in range(3)]
-                for c in more:
-                    c.set_option(rt.OPT_TIMING, 0)
-                out["share_ms_4_in_flight"] = share_table([ctx] + more, wl, a.band_rows, torch, dev)
-                for c in more:
-                    c.close()
+                out["share_ms"] = share_table(ctx, 1, wl, a.band_rows, torch, dev)
+                out["share_ms_4_in_flight"] = share_table(ctx, 4, wl, a.band_rows, torch, dev)
             if a.workload == "sponza":
                 # the second stand-in (irregular triangle sizes, slivers, overlapping cloth) through the same loop
                 wl2 = workloads.atrium2(W=wl.W, H=wl.H, max_depth=wl.max_depth)

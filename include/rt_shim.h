@@ -204,6 +204,17 @@ int rt_render_frame_planes(rt_ctx *ctx, int W, int H, int y0, int y1, int max_de
 int rt_render_rows_device(rt_ctx *ctx, int W, int H, const rt_rowset *rows, int max_depth,
                           void *d_rgb8, void *d_hit_id, void *d_rgb32, void *d_hit_t, void *stream);
 
+/* Frames in flight.  No counterpart in the reference (its setup() renders one frame, main.cpp:262-277).  The same call
+ * as rt_render_rows_device on frame slot `slot` (0 <= slot < RT_MAX_FRAME_SLOTS; rt_render_rows_device is slot 0).
+ * Every slot has its own workspace (ray queues, hit and occlusion planes, counters), captured graph and completion
+ * event, so frames of DIFFERENT slots may be in flight at the same time on different streams over one scene and one
+ * hierarchy; frames of one slot are ordered one behind the other.  A rank's share of a partitioned frame is too small to
+ * fill the GPU (fewer rays than resident lanes, six dependent launches): two to four slots nearly double its frame
+ * rate.  rt_get_stats reports the slot rendered last; the scene-changing calls wait for every slot. */
+#define RT_MAX_FRAME_SLOTS 8
+int rt_render_rows_device_slot(rt_ctx* ctx, int slot, int W, int H, const rt_rowset* rows, int max_depth,
+                               void* d_rgb8, void* d_hit_id, void* d_rgb32, void* d_hit_t, void* stream);
+
 /* The same frame as rt_render_rows_device for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
  * reference, which allocates its one image with `new` (Raytracer/main.cpp:259) and nothing per ray.

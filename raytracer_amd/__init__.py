@@ -30,8 +30,9 @@ ABI_SYMBOLS = (
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
     "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals", "rt_set_triangle_texcoords",
-    "rt_render_rows_device_noalloc",
+    "rt_render_rows_device_noalloc", "rt_render_rows_device_slot",
 )
+MAX_FRAME_SLOTS = 8
 NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
@@ -176,6 +177,7 @@ def load_library():
     L.rt_render_frame_planes.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(FramePlanes)]
     L.rt_render_rows_device.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
     L.rt_render_rows_device_noalloc.argtypes = [vp, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
+    L.rt_render_rows_device_slot.argtypes = [vp, i32, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
     L.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_synchronize.argtypes = [vp]
@@ -292,10 +294,15 @@ class Context:
         return out
 
     def render_rows_device(self, W, H, rowset, max_depth, d_rgb8=None, d_hit_id=None, d_rgb32=None, d_hit_t=None,
-                           stream=None):
-        """rt_render_rows_device: raw device pointers (ints), asynchronous on `stream`."""
-        self._check(self.L.rt_render_rows_device(self._h, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id, d_rgb32,
-                                                 d_hit_t, stream))
+                           stream=None, slot=0):
+        """rt_render_rows_device (slot 0) / rt_render_rows_device_slot: raw device pointers (ints), asynchronous on
+        `stream`.  Frames of different slots may be in flight at the same time (on different streams)."""
+        if slot:
+            self._check(self.L.rt_render_rows_device_slot(self._h, slot, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id,
+                                                          d_rgb32, d_hit_t, stream))
+        else:
+            self._check(self.L.rt_render_rows_device(self._h, W, H, C.byref(rowset), max_depth, d_rgb8, d_hit_id, d_rgb32,
+                                                     d_hit_t, stream))
 
     def render_rows_device_noalloc(self, W, H, rowset, max_depth, d_rgb8=None, d_hit_id=None, d_rgb32=None, d_hit_t=None,
                                    stream=None):

@@ -49,6 +49,28 @@ int fail(int code, const std::string &msg)
 
 }  // namespace
 
+// What one frame in flight owns.
+struct FrameSlot {
+    FrameWorkspace ws;
+    // replay of the last frame's launches (RT_OPT_GRAPH)
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<unsigned char> graph_key;
+    std::vector<unsigned char> last_key;     // the previous frame's key, captured or not
+    // last frame
+    bool frame_valid = false;
+    int last_levels = 0, last_launches = 0, last_accel = 0;
+    bool last_wavefront = false;
+    bool last_timed = false;                 // the last frame recorded its device events
+    uint64_t last_primary = 0;
+    FrameCounters *last_counters = nullptr;  // where the last frame counted its rays (the workspace, or the scratch array)
+    // Renders are asynchronous and may run on a caller's stream: frame_done is recorded behind every enqueued
+    // frame, and everything that rewrites what a frame reads (scene, hierarchy, workspace, the captured graph)
+    // waits for it first.
+    hipEvent_t frame_done = nullptr;
+    bool frame_pending = false;
+    hipStream_t last_stream = nullptr;
+};
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -70,27 +92,14 @@ struct rt_ctx {
     // options
     int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0, opt_split = 0;
     DevCamera cam;
-    FrameWorkspace ws;
-    // replay of the last frame's launches (RT_OPT_GRAPH, only with timing and test counting off)
-    int opt_graph = 1;
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<unsigned char> graph_key;
-    std::vector<unsigned char> last_key;     // the previous frame's key, captured or not
+    int opt_graph = 1;                       // replay of an unchanged frame's launches (only with timing and test counting off)
     unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
-    // last frame
-    bool frame_valid = false;
-    int last_levels = 0, last_launches = 0, last_accel = 0;
-    bool last_wavefront = false;
-    bool last_timed = false;                 // the last frame recorded its device events
-    uint64_t last_primary = 0;
     unsigned char *scratch_ptr = nullptr;    // this device's copy of the no-alloc scratch array (set by rt_create)
-    FrameCounters *last_counters = nullptr;  // where the last frame counted its rays (the workspace, or the scratch array)
-    // Renders are asynchronous and may run on a caller's stream: frame_done is recorded behind every enqueued
-    // frame, and everything that rewrites what a frame reads (scene, hierarchy, workspace, the captured graph)
-    // waits for it first.
-    hipEvent_t frame_done = nullptr;
-    bool frame_pending = false;
-    hipStream_t last_stream = nullptr;
+    // Frames in flight: every slot has a workspace, a captured graph and a completion event of its own, so frames of
+    // different slots may run side by side on different streams; f is the slot of the frame at hand (and afterwards
+    // of the last one, which rt_get_stats reports).
+    FrameSlot slots[RT_MAX_FRAME_SLOTS];
+    FrameSlot *f = &slots[0];
 };
 
 namespace {
@@ -130,16 +139,23 @@ struct DeviceGuard {
 void quiesce(rt_ctx *c)
 {
     (void)hipStreamSynchronize(c->stream);
-    if (c->frame_pending && c->frame_done) (void)hipEventSynchronize(c->frame_done);
-    c->frame_pending = false;
+    for (FrameSlot &f : c->slots) {
+        if (f.frame_pending && f.frame_done) (void)hipEventSynchronize(f.frame_done);
+        f.frame_pending = false;
+    }
 }
 
-void drop_graph(rt_ctx *c)
+void drop_graph(FrameSlot &f)
 {
-    if (c->graph_exec && c->frame_pending && c->frame_done) (void)hipEventSynchronize(c->frame_done);   // it may still be replaying
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    c->graph_exec = nullptr;
-    c->graph_key.clear();
+    if (f.graph_exec && f.frame_pending && f.frame_done) (void)hipEventSynchronize(f.frame_done);   // it may still be replaying
+    if (f.graph_exec) (void)hipGraphExecDestroy(f.graph_exec);
+    f.graph_exec = nullptr;
+    f.graph_key.clear();
+}
+
+void drop_graphs(rt_ctx *c)
+{
+    for (FrameSlot &f : c->slots) drop_graph(f);
 }
 
 
@@ -178,7 +194,7 @@ void free_workspace(FrameWorkspace &ws)
 int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pipe, bool host_outputs)
 {
     const bool wavefront = pipe == 2;
-    FrameWorkspace &ws = c->ws;
+    FrameWorkspace &ws = c->f->ws;
     // (hipFree of a buffer waits for the device by itself; the frees below are the only way a buffer goes away)
     // frame counters + claim cursors: one block, cleared by one memset per frame
     {
@@ -347,12 +363,14 @@ DevScene device_scene(const rt_ctx *c, int accel)
 }
 
 int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
-                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false)
+                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false, int slot = 0)
 {
+    if (slot < 0 || slot >= RT_MAX_FRAME_SLOTS) return fail(RT_E_INVALID, "frame slot out of range");
     if (int rc = validate_rows(W, H, rows)) return rc;
     if (max_depth < 0 || max_depth > RT_MAX_DEPTH) return fail(RT_E_INVALID, "max_depth out of range");
     if (c->n_analytic == 0 && c->n_tris == 0) return fail(RT_E_STATE, "no scene set");
-    c->frame_valid = false;
+    c->f = &c->slots[slot];
+    c->f->frame_valid = false;
     const size_t pixels = (size_t)W * (size_t)rows->n_rows;
     if (pixels == 0) return RT_OK;
     int accel = 0;
@@ -361,8 +379,8 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     const bool wavefront = pipe != 1;
     const size_t slots = (size_t)((W + 7) / 8) * (size_t)((rows->n_rows + 7) / 8) * 64;
     if (int rc = ensure_workspace(c, pixels, slots, max_depth + 1, pipe, host_outputs)) return rc;
-    // one workspace serves every frame of this context: a frame on another stream than the last one waits for it
-    if (c->frame_pending && stream != c->last_stream && hipStreamWaitEvent(stream, c->frame_done, 0) != hipSuccess)
+    // one workspace serves every frame of this slot: a frame on another stream than the slot's last one waits for it
+    if (c->f->frame_pending && stream != c->f->last_stream && hipStreamWaitEvent(stream, c->f->frame_done, 0) != hipSuccess)
         return fail(RT_E_DEVICE, "hipStreamWaitEvent failed");
 
     const DevScene sc = device_scene(c, accel);
@@ -375,12 +393,12 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     fp.pipeline = c->opt_pipeline;
     fp.d_normal = nullptr;
     fp.d_uv = nullptr;
-    if (host_outputs) { d_rgb8 = c->ws.out_rgb8; d_hit_id = c->ws.out_id; d_rgb32 = c->ws.out_rgb32; }
+    if (host_outputs) { d_rgb8 = c->f->ws.out_rgb8; d_hit_id = c->f->ws.out_id; d_rgb32 = c->f->ws.out_rgb32; }
     if (host_aov) {
-        if (!c->ws.out_normal || c->ws.out_cap < pixels) return fail(RT_E_STATE, "plane staging missing");
-        d_hit_t = c->ws.hit_t;
-        fp.d_normal = c->ws.out_normal;
-        fp.d_uv = c->ws.out_uv;
+        if (!c->f->ws.out_normal || c->f->ws.out_cap < pixels) return fail(RT_E_STATE, "plane staging missing");
+        d_hit_t = c->f->ws.hit_t;
+        fp.d_normal = c->f->ws.out_normal;
+        fp.d_uv = c->f->ws.out_uv;
     }
     std::string err;
     int launches = 0;
@@ -395,59 +413,59 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         memset(&key, 0, sizeof key);
         key.fp = fp; key.sc = sc; key.cam = c->cam;
         key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
-        void *wsp[16] = { c->ws.records, c->ws.queue_o[0], c->ws.queue_o[1], c->ws.queue_d[0], c->ws.queue_d[1], c->ws.counters,
-                          c->ws.p_hits, c->ws.p_occ, c->ws.sq_o, nullptr, c->ws.trace_cursors, c->ws.overflow,
-                          c->ws.rq_counts[0], c->ws.rq_counts[1], c->ws.sq_counts, c->ws.hit_t };
+        void *wsp[16] = { c->f->ws.records, c->f->ws.queue_o[0], c->f->ws.queue_o[1], c->f->ws.queue_d[0], c->f->ws.queue_d[1], c->f->ws.counters,
+                          c->f->ws.p_hits, c->f->ws.p_occ, c->f->ws.sq_o, nullptr, c->f->ws.trace_cursors, c->f->ws.overflow,
+                          c->f->ws.rq_counts[0], c->f->ws.rq_counts[1], c->f->ws.sq_counts, c->f->ws.hit_t };
         memcpy(key.ws, wsp, sizeof wsp);
         key.version = c->state_version;
-        const bool same = c->graph_exec && c->graph_key.size() == sizeof key && memcmp(c->graph_key.data(), &key, sizeof key) == 0;
+        const bool same = c->f->graph_exec && c->f->graph_key.size() == sizeof key && memcmp(c->f->graph_key.data(), &key, sizeof key) == 0;
         // A frame that differs from the last one (moving camera, moving geometry) is launched directly; the
         // capture is made when the same frame is asked for a second time in a row, so that a changing frame
         // never pays for a capture it will not replay.
-        const bool repeat = c->last_key.size() == sizeof key && memcmp(c->last_key.data(), &key, sizeof key) == 0;
-        c->last_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
+        const bool repeat = c->f->last_key.size() == sizeof key && memcmp(c->f->last_key.data(), &key, sizeof key) == 0;
+        c->f->last_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
         if (!same) {
-            drop_graph(c);
+            drop_graph(*c->f);
             hipGraph_t graph = nullptr;
             if (repeat && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, c->stream, &launches, &err);
+                rc = trace_frame(sc, c->cam, fp, c->f->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, c->stream, &launches, &err);
                 const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
                 if (rc == RT_OK && ee == hipSuccess && graph &&
-                    hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    c->graph_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
-                    c->last_launches = launches;
+                    hipGraphInstantiate(&c->f->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    c->f->graph_key.assign((const unsigned char *)&key, (const unsigned char *)&key + sizeof key);
+                    c->f->last_launches = launches;
                 } else {
-                    c->graph_exec = nullptr;
+                    c->f->graph_exec = nullptr;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
                 (void)hipGetLastError();
             }
             if (rc != RT_OK) return fail(rc, err);
         }
-        if (c->graph_exec) {
-            if (hipGraphLaunch(c->graph_exec, stream) != hipSuccess) {
-                drop_graph(c);
+        if (c->f->graph_exec) {
+            if (hipGraphLaunch(c->f->graph_exec, stream) != hipSuccess) {
+                drop_graph(*c->f);
                 return fail(RT_E_DEVICE, "hipGraphLaunch failed");
             }
-            launches = c->last_launches;
+            launches = c->f->last_launches;
         } else {
-            rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+            rc = trace_frame(sc, c->cam, fp, c->f->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
         }
     } else {
-        rc = trace_frame(sc, c->cam, fp, c->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
+        rc = trace_frame(sc, c->cam, fp, c->f->ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &launches, &err);
     }
     if (rc != RT_OK) return fail(rc, err);
-    if (hipEventRecord(c->frame_done, stream) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
-    c->frame_pending = true;
-    c->last_stream = stream;
-    c->last_counters = c->ws.counters;
-    c->last_timed = fp.timing != 0;
-    c->frame_valid = true;
-    c->last_levels = max_depth + 1;
-    c->last_launches = launches;
-    c->last_accel = accel;
-    c->last_wavefront = wavefront;
-    c->last_primary = pixels;
+    if (hipEventRecord(c->f->frame_done, stream) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
+    c->f->frame_pending = true;
+    c->f->last_stream = stream;
+    c->f->last_counters = c->f->ws.counters;
+    c->f->last_timed = fp.timing != 0;
+    c->f->frame_valid = true;
+    c->f->last_levels = max_depth + 1;
+    c->f->last_launches = launches;
+    c->f->last_accel = accel;
+    c->f->last_wavefront = wavefront;
+    c->f->last_primary = pixels;
     return RT_OK;
 }
 
@@ -490,11 +508,15 @@ rt_ctx *rt_create(int device_ordinal)
             return nullptr;
         }
     }
-    if (hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming) != hipSuccess) {
-        fail(RT_E_DEVICE, "hipEventCreate failed");
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        return nullptr;
+    for (FrameSlot &f : c->slots) {
+        if (hipEventCreateWithFlags(&f.frame_done, hipEventDisableTiming) != hipSuccess) {
+            fail(RT_E_DEVICE, "hipEventCreate failed");
+            for (FrameSlot &g2 : c->slots)
+                if (g2.frame_done) (void)hipEventDestroy(g2.frame_done);
+            (void)hipStreamDestroy(c->stream);
+            delete c;
+            return nullptr;
+        }
     }
     default_camera(&c->cam);
     return c;
@@ -505,13 +527,14 @@ void rt_destroy(rt_ctx *c)
     if (!c) return;
     DeviceGuard g(c->device);
     quiesce(c);
-    drop_graph(c);
+    drop_graphs(c);
     free_triangles(c);
-    free_workspace(c->ws);
+    for (FrameSlot &f : c->slots) free_workspace(f.ws);
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->frame_done) (void)hipEventDestroy(c->frame_done);
+    for (FrameSlot &f : c->slots)
+        if (f.frame_done) (void)hipEventDestroy(f.frame_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -538,7 +561,7 @@ int rt_set_option(rt_ctx *c, int option, int value)
         if (value < 0 || value > 32) return fail(RT_E_INVALID, "RT_OPT_SPLIT takes 0..32");
         c->opt_split = value;
         return RT_OK;
-    case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graph(c); return RT_OK;
+    case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graphs(c); return RT_OK;
     case RT_OPT_PIPELINE:
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
         c->opt_pipeline = value;
@@ -685,7 +708,7 @@ void *stage(rt_ctx *c, size_t bytes)
 int after_vertex_update(rt_ctx *c)
 {
     c->state_version++;
-    c->frame_valid = false;
+    for (FrameSlot &f : c->slots) f.frame_valid = false;
     if (c->bvh.wnodes && c->bvh.leaf_max == c->opt_leaf_max && c->bvh.builder == c->opt_builder && c->bvh.split == split_cells(c)) {
         std::string err;
         int rc = lbvh_refit(c->d_tri_mt, c->n_tris, c->stream, &c->bvh, &err);
@@ -844,11 +867,11 @@ int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint
     const size_t pixels = (size_t)W * (size_t)(y1 - y0);
     hipError_t e = hipSuccess;
     if (pixels) {
-        if (rgb8) e = hipMemcpyAsync(rgb8, c->ws.out_rgb8, 3 * pixels, hipMemcpyDeviceToHost, c->stream);
+        if (rgb8) e = hipMemcpyAsync(rgb8, c->f->ws.out_rgb8, 3 * pixels, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && hit_id)
-            e = hipMemcpyAsync(hit_id, c->ws.out_id, sizeof(int32_t) * pixels, hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && rgb32)
-            e = hipMemcpyAsync(rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels, hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
@@ -868,12 +891,12 @@ int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_dept
     auto pull = [&](void *dst, const void *src, size_t bytes) {
         if (e == hipSuccess && dst && pixels) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
     };
-    pull(out->rgb8, c->ws.out_rgb8, 3 * pixels);
-    pull(out->hit_id, c->ws.out_id, sizeof(int32_t) * pixels);
-    pull(out->rgb32, c->ws.out_rgb32, sizeof(float) * 3 * pixels);
-    pull(out->hit_t, c->ws.hit_t, sizeof(float) * pixels);
-    pull(out->normal, c->ws.out_normal, sizeof(float) * 3 * pixels);
-    pull(out->uv, c->ws.out_uv, sizeof(float) * 2 * pixels);
+    pull(out->rgb8, c->f->ws.out_rgb8, 3 * pixels);
+    pull(out->hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels);
+    pull(out->rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels);
+    pull(out->hit_t, c->f->ws.hit_t, sizeof(float) * pixels);
+    pull(out->normal, c->f->ws.out_normal, sizeof(float) * 3 * pixels);
+    pull(out->uv, c->f->ws.out_uv, sizeof(float) * 2 * pixels);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
     return RT_OK;
@@ -882,10 +905,16 @@ int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_dept
 int rt_render_rows_device(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
                           void *d_rgb32, void *d_hit_t, void *stream)
 {
+    return rt_render_rows_device_slot(c, 0, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream);
+}
+
+int rt_render_rows_device_slot(rt_ctx *c, int slot, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
+                               void *d_rgb32, void *d_hit_t, void *stream)
+{
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return render_common(c, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, false);
+    return render_common(c, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, false, false, slot);
 }
 
 // The frame of rt_render_rows_device through the one-kernel-per-bounce-level pipeline, with every intermediate
@@ -901,7 +930,8 @@ int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows
     if (c->n_analytic == 0 && c->n_tris == 0) return fail(RT_E_STATE, "no scene set");
     if (!c->scratch_ptr) return fail(RT_E_STATE, "no scratch array on this device");
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    c->frame_valid = false;
+    c->f = &c->slots[0];
+    c->f->frame_valid = false;
     const size_t pixels = (size_t)W * (size_t)rows->n_rows;
     if (pixels == 0) return RT_OK;
     // the hierarchy is built when the mesh is set; building it here would allocate
@@ -956,25 +986,25 @@ int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (!capturing && c->frame_pending && s != c->last_stream && hipStreamWaitEvent(s, c->frame_done, 0) != hipSuccess)
+    if (!capturing && c->f->frame_pending && s != c->f->last_stream && hipStreamWaitEvent(s, c->f->frame_done, 0) != hipSuccess)
         return fail(RT_E_DEVICE, "hipStreamWaitEvent failed");
     std::string err;
     int launches = 0;
     const int rc = trace_frame(sc, c->cam, fp, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, &launches, &err);
     if (rc != RT_OK) return fail(rc, err);
     if (!capturing) {
-        if (hipEventRecord(c->frame_done, s) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
-        c->frame_pending = true;
-        c->last_stream = s;
+        if (hipEventRecord(c->f->frame_done, s) != hipSuccess) return fail(RT_E_DEVICE, "hipEventRecord failed");
+        c->f->frame_pending = true;
+        c->f->last_stream = s;
     }
-    c->last_counters = ws.counters;
-    c->last_timed = false;
-    c->frame_valid = true;
-    c->last_levels = max_depth + 1;
-    c->last_launches = launches;
-    c->last_accel = accel;
-    c->last_wavefront = false;
-    c->last_primary = pixels;
+    c->f->last_counters = ws.counters;
+    c->f->last_timed = false;
+    c->f->frame_valid = true;
+    c->f->last_levels = max_depth + 1;
+    c->f->last_launches = launches;
+    c->f->last_accel = accel;
+    c->f->last_wavefront = false;
+    c->f->last_primary = pixels;
     return RT_OK;
 }
 
@@ -1021,13 +1051,13 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->ms_build = c->bvh.ms_build;
     out->bvh_sah_cost = c->bvh.sah_cost;
     out->bvh_refs = c->bvh.n_refs;
-    if (!c->frame_valid) return RT_OK;
+    if (!c->f->frame_valid) return RT_OK;
     FrameCounters fc;
-    if (hipMemcpy(&fc, c->last_counters ? c->last_counters : c->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(&fc, c->f->last_counters ? c->f->last_counters : c->f->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(RT_E_DEVICE, "read frame counters");
     if (fc.guard_hits)      // only a guarded build (-DRT_GUARD=1) ever counts these
         return fail(RT_E_DEVICE, "guarded build: " + std::to_string(fc.guard_hits) + " out-of-range indices were caught in the last frame");
-    out->rays_primary = c->last_primary;
+    out->rays_primary = c->f->last_primary;
     out->rays_shadow = fc.rays_shadow;
     out->rays_reflect = fc.rays_reflect;
     out->box_tests = fc.box_tests;
@@ -1044,20 +1074,20 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
         for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", fc.step_hist[k]);
         fprintf(stderr, "\n");
     }
-    out->n_launches = c->last_launches;
-    out->accel = c->last_accel;
-    const int ne = c->ws.n_events;
-    if (c->last_timed && ne >= 3 && (int)c->ws.events.size() >= ne) {
+    out->n_launches = c->f->last_launches;
+    out->accel = c->f->last_accel;
+    const int ne = c->f->ws.n_events;
+    if (c->f->last_timed && ne >= 3 && (int)c->f->ws.events.size() >= ne) {
         // events: [start] [after each traversal stage] ... [after the final fold]
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)ne - 2]) == hipSuccess) out->ms_trace = ms;
-        if (hipEventElapsedTime(&ms, c->ws.events[(size_t)ne - 2], c->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_resolve = ms;
-        if (hipEventElapsedTime(&ms, c->ws.events[0], c->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_frame = ms;
+        if (hipEventElapsedTime(&ms, c->f->ws.events[0], c->f->ws.events[(size_t)ne - 2]) == hipSuccess) out->ms_trace = ms;
+        if (hipEventElapsedTime(&ms, c->f->ws.events[(size_t)ne - 2], c->f->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_resolve = ms;
+        if (hipEventElapsedTime(&ms, c->f->ws.events[0], c->f->ws.events[(size_t)ne - 1]) == hipSuccess) out->ms_frame = ms;
         out->ms_traverse = out->ms_trace;
-        if (c->last_wavefront && c->ws.trav_pairs > 0 && (int)c->ws.trav_events.size() >= 2 * c->ws.trav_pairs) {
+        if (c->f->last_wavefront && c->f->ws.trav_pairs > 0 && (int)c->f->ws.trav_events.size() >= 2 * c->f->ws.trav_pairs) {
             float tv = 0.f;
-            for (int k = 0; k < c->ws.trav_pairs; k++)
-                if (hipEventElapsedTime(&ms, c->ws.trav_events[2 * (size_t)k], c->ws.trav_events[2 * (size_t)k + 1]) == hipSuccess) tv += ms;
+            for (int k = 0; k < c->f->ws.trav_pairs; k++)
+                if (hipEventElapsedTime(&ms, c->f->ws.trav_events[2 * (size_t)k], c->f->ws.trav_events[2 * (size_t)k + 1]) == hipSuccess) tv += ms;
             out->ms_traverse = tv;
         }
     }

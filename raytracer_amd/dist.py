@@ -77,10 +77,10 @@ class Frame:
 
 
 class _Slot:
-    """What one frame in flight owns: a context (scene copy, workspace, captured graph), a stream, its buffers."""
+    """What one frame in flight owns: a frame slot of a context (workspace, captured graph), a stream, its buffers."""
 
-    def __init__(self, ctx, stream, local, gathered, frame):
-        self.ctx, self.stream, self.local, self.gathered, self.frame = ctx, stream, local, gathered, frame
+    def __init__(self, ctx, index, stream, local, gathered, frame):
+        self.ctx, self.index, self.stream, self.local, self.gathered, self.frame = ctx, index, stream, local, gathered, frame
 
 
 class PartitionedRenderer:
@@ -94,9 +94,11 @@ class PartitionedRenderer:
     makes the caller's current stream wait for the frame, so whoever consumes the tensor there sees the
     finished frame without any device-wide synchronisation.  render() is the two together.
 
-    Frames in flight: `ctx` may be a sequence of contexts holding the same scene.  Each is one slot with its
-    own stream and buffers, frames go to the slots round-robin, and a caller that waits for a frame only
-    when it needs it (render_async now, Frame.wait() a few frames later) keeps len(ctx) frames in flight.
+    Frames in flight: `frames_in_flight` = N gives N slots, each a frame slot of the context
+    (rt_render_rows_device_slot: own workspace and captured graph over ONE scene and hierarchy) with its own
+    stream and buffers; frames go to the slots round-robin, and a caller that waits for a frame only when it
+    needs it (render_async now, Frame.wait() a few frames later) keeps N frames in flight.  (`ctx` may also be a
+    sequence of contexts holding the same scene: one slot per context.)
     The slots' collectives share one further stream, so they run one at a time and in frame order on every rank.
     One rank's share of a small frame has fewer rays than the GPU has lanes and six dependent traversal
     launches, each as long as its longest rays: a second and third frame fill what one leaves idle (an
@@ -107,26 +109,29 @@ class PartitionedRenderer:
     (and a CPU device) runs the very same partition / gather / reassembly logic without a GPU."""
 
     def __init__(self, ctx, W, H, max_depth, rank=0, world=1, band_rows=DEFAULT_BAND_ROWS, device=None,
-                 render_rows=None, deinterleave=None, dist=None):
+                 render_rows=None, deinterleave=None, dist=None, frames_in_flight=1):
         import torch
         self.torch = torch
-        ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+        if isinstance(ctx, (list, tuple)):
+            ctxs = [(c, 0) for c in ctx]
+        else:
+            ctxs = [(ctx, k) for k in range(max(int(frames_in_flight), 1))]
         if not ctxs:
             raise ValueError("PartitionedRenderer needs at least one context")
-        self.ctx, self.W, self.H, self.max_depth = ctxs[0], W, H, max_depth
+        self.ctx, self.W, self.H, self.max_depth = ctxs[0][0], W, H, max_depth
         self.rank, self.world, self.band_rows = rank, world, band_rows
         self.rowset = band_rowset(H, band_rows, rank, world) if world > 1 else RowSet(0, 1, 1, H)
         self.cap_rows = rows_per_part(H, band_rows, world) if world > 1 else H
-        dev = device if device is not None else torch.device("cuda", ctxs[0].device)
+        dev = device if device is not None else torch.device("cuda", ctxs[0][0].device)
         self.device = torch.device(dev)
         self.on_gpu = self.device.type == "cuda"
         if world > 1 and dist is None:
             import torch.distributed as dist
         self.dist = dist
         self.slots = []
-        for c in ctxs:
+        for c, index in ctxs:
             self.slots.append(_Slot(
-                c, torch.cuda.Stream(device=self.device) if self.on_gpu else None,
+                c, index, torch.cuda.Stream(device=self.device) if self.on_gpu else None,
                 torch.zeros((self.cap_rows, W, 3), dtype=torch.uint8, device=self.device),
                 torch.empty((world * self.cap_rows, W, 3), dtype=torch.uint8, device=self.device) if world > 1 else None,
                 torch.empty((H, W, 3), dtype=torch.uint8, device=self.device) if (world > 1 and rank == 0) else None))
@@ -156,7 +161,7 @@ class PartitionedRenderer:
             self._render_rows(self.rowset, slot.local)
         else:
             slot.ctx.render_rows_device(self.W, self.H, self.rowset, self.max_depth, d_rgb8=slot.local.data_ptr(),
-                                        stream=self._handle(slot))
+                                        stream=self._handle(slot), slot=slot.index)
         if self.world == 1:
             return slot.local
         # on a GPU the collective takes its order from the current stream

@@ -47,8 +47,8 @@ def _worker(rank, world, port, W, H, band, q, slots=1):
             cap = rt.rows_per_part(H, band, world)
             frame.copy_(torch.from_numpy(deinterleave_numpy(gathered.numpy().reshape(world, cap, W, 3), H, band)))
 
-        pr = PartitionedRenderer([None] * slots if slots > 1 else None, W, H, DEPTH, rank, world, band, torch.device("cpu"),
-                                 render_rows=render_rows, deinterleave=deinterleave, dist=dist)
+        pr = PartitionedRenderer(None, W, H, DEPTH, rank, world, band, torch.device("cpu"),
+                                 render_rows=render_rows, deinterleave=deinterleave, dist=dist, frames_in_flight=slots)
         assert pr.frames_in_flight == slots
         if slots > 1:
             # frames in flight: three frames asked for before the first is looked at go to slots 0, 1, 0, each with

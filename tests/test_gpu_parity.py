@@ -1014,6 +1014,49 @@ def test_frames_in_flight_each_hold_their_own_frame():
             c.close()
 
 
+def test_frame_slots_of_one_context_keep_frames_apart():
+    """One context, one scene, one hierarchy, three frame slots (rt_render_rows_device_slot): the camera changes before
+    every enqueue, seven frames are enqueued on three streams before the first is waited for, and every slot's
+    buffer holds the picture of the camera its frames were enqueued with.  A vertex update then has to wait for all
+    three slots before it overwrites the triangles they read."""
+    import torch
+    from raytracer_amd.dist import PartitionedRenderer
+    spec = atrium_spec(detail=0.02)
+    W, H, D = 320, 200, 2
+    cams = [rt.Camera(origin=(0.3 * k - 0.3, -1.5 + 0.2 * k, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4) for k in range(3)]
+    with rt.Context(0) as ctx:
+        to_product(ctx, spec)
+        ctx.set_option(rt.OPT_TIMING, 0)
+        want = []
+        for cam in cams:
+            ctx.set_camera(cam)
+            want.append(ctx.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"])
+        pr = PartitionedRenderer(ctx, W, H, D, frames_in_flight=3)
+        assert pr.frames_in_flight == 3 and [s.index for s in pr.slots] == [0, 1, 2]
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            frames = []
+            for k in range(7):
+                ctx.set_camera(cams[k % 3])
+                frames.append(pr.render_async())
+            # moving the mesh must not touch what the seven frames in flight still read
+            moved = _moved(spec.verts, 1)
+            ctx.update_mesh_vertices(moved)
+            hosts = [f.wait().cpu().numpy().copy() for f in frames]
+        for k, h in enumerate(hosts):
+            assert np.array_equal(h, want[k % 3]), k
+        assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+        # and after the update every slot renders the moved mesh
+        ctx.set_camera(cams[0])
+        after = [pr.render(slot=k).cpu().numpy().copy() for k in range(3)]
+        fresh = ctx.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"]
+        for a in after:
+            assert np.array_equal(a, fresh)
+        assert not np.array_equal(fresh, want[0])
+        with pytest.raises(rt.RtError):
+            ctx.render_rows_device(W, H, rt.RowSet(0, 1, 1, H), D, d_rgb8=pr.slots[0].local.data_ptr(), slot=rt.MAX_FRAME_SLOTS)
+
+
 def _wires_and_walls_spec():
     """What whole-triangle boxes handle worst: long thin triangles that cross the scene diagonally, a huge
     two-triangle wall and floor, and small triangles scattered in the space their boxes cover."""

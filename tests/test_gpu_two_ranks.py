@@ -31,7 +31,7 @@ from raytracer_amd.dist import HostStagedGather as _HostStagedGather
 
 
 def _worker_in_flight(rank, world, port, q):
-    """Two frame slots per rank, a camera per slot, five frames asked for before the first is waited for."""
+    """Two frame slots of one context per rank, a camera per slot, five frames asked for before the first is waited for."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -39,22 +39,23 @@ def _worker_in_flight(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        ctxs = [rt.Context(0) for _ in range(2)]
-        for c, cam in zip(ctxs, _cams()):
-            to_product(c, atrium_spec(detail=0.02))
-            c.set_option(rt.OPT_TIMING, 0)
-            c.set_camera(cam)
-        pr = PartitionedRenderer(ctxs, W, H, D, rank, world, BAND, torch.device("cuda", 0), dist=_HostStagedGather(dist, torch))
-        assert pr.gather_stream is not None and pr.gather_stream is not pr.stream
-        with torch.cuda.stream(torch.cuda.Stream()):
-            frames = [pr.render_async() for _ in range(5)]
-            outs = [f.wait() for f in frames]
-            torch.cuda.current_stream().synchronize()
-            if rank == 0:
-                q.put([outs[0].cpu().numpy().copy(), outs[1].cpu().numpy().copy(), outs[4].cpu().numpy().copy()])
-        dist.barrier()
-        for c in ctxs:
-            c.close()
+        with rt.Context(0) as ctx:
+            to_product(ctx, atrium_spec(detail=0.02))
+            ctx.set_option(rt.OPT_TIMING, 0)
+            pr = PartitionedRenderer(ctx, W, H, D, rank, world, BAND, torch.device("cuda", 0), dist=_HostStagedGather(dist, torch),
+                                     frames_in_flight=2)
+            assert pr.gather_stream is not None and pr.gather_stream is not pr.stream
+            cams = _cams()
+            with torch.cuda.stream(torch.cuda.Stream()):
+                frames = []
+                for k in range(5):
+                    ctx.set_camera(cams[k % 2])          # slot k % 2 always gets camera k % 2
+                    frames.append(pr.render_async())
+                outs = [f.wait() for f in frames]
+                torch.cuda.current_stream().synchronize()
+                if rank == 0:
+                    q.put([outs[0].cpu().numpy().copy(), outs[1].cpu().numpy().copy(), outs[4].cpu().numpy().copy()])
+            dist.barrier()
     finally:
         dist.destroy_process_group()
 
