@@ -40,6 +40,20 @@ def test_null_context_is_rejected_without_touching_a_gpu():
     assert L.rt_set_option(None, rt.OPT_ACCEL, 0) == -1
     assert b"null" in L.rt_last_error()
     assert L.rt_render_frame(None, 8, 8, 0, 8, 1, None, None, None) == -1
+    rs = rt.RowSet(0, 1, 1, 8)
+    assert L.rt_render_rows_device_slot(None, 1, 8, 8, rs, 1, None, None, None, None, None) == -1
+    assert L.rt_render_rows_device_noalloc(None, 8, 8, rs, 1, None, None, None, None, None) == -1
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers must compile as strict C99 (a C translation unit that calls through them,
+    warnings as errors)."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rt_shim.h"\n#include "rt_objhost.h"\n'
+                   'int main(void) { rt_rowset r = { 0, 1, 1, 8 };\n'
+                   '  return rt_abi_version() > 0 && rt_render_rows_device_slot(0, RT_MAX_FRAME_SLOTS - 1, 8, 8, &r, 1, 0, 0, 0, 0, 0) == RT_E_INVALID ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)], check=True)
 
 
 def _dump(path):
