@@ -115,7 +115,10 @@ class PartitionedRenderer:
         if isinstance(ctx, (list, tuple)):
             ctxs = [(c, 0) for c in ctx]
         else:
-            ctxs = [(ctx, k) for k in range(max(int(frames_in_flight), 1))]
+            from . import MAX_FRAME_SLOTS
+            if not 1 <= int(frames_in_flight) <= MAX_FRAME_SLOTS:
+                raise ValueError("frames_in_flight must be 1..%d (the context's frame slots)" % MAX_FRAME_SLOTS)
+            ctxs = [(ctx, k) for k in range(int(frames_in_flight))]
         if not ctxs:
             raise ValueError("PartitionedRenderer needs at least one context")
         self.ctx, self.W, self.H, self.max_depth = ctxs[0][0], W, H, max_depth

@@ -98,6 +98,8 @@ def test_single_process_renderer_and_reduction_need_no_process_group():
     calls = []
     pr = PartitionedRenderer(None, W, H, 1, 0, 1, 8, torch.device("cpu"), render_rows=lambda rs, out: calls.append((rs.first_band, rs.band_rows, rs.band_stride, rs.n_rows)))
     assert pr.render() is pr.local and calls == [(0, 1, 1, H)]
+    with pytest.raises(ValueError):
+        PartitionedRenderer(None, W, H, 1, 0, 1, 8, torch.device("cpu"), frames_in_flight=rt.MAX_FRAME_SLOTS + 1)
     v = torch.tensor([1.0, 2.0], dtype=torch.float64)
     mx, sm = reduce_over_ranks(v, None)
     assert torch.equal(mx, v) and torch.equal(sm, v)
