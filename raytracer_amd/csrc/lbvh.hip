@@ -940,7 +940,7 @@ __device__ void lattice_box(const float4 lo, const float4 hi, const float *gb, c
 __device__ __forceinline__ int emit_wide_node(int i, const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
                             const int4 *__restrict__ wkids, int n, int leaf_max, const float4 *__restrict__ box_lo,
                             const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
-                            const int *__restrict__ slot, BvhNode4 *wnodes)
+                            const int *__restrict__ slot, BvhNode4 *wnodes, BvhNode4F *fnodes)
 {
     if (i >= n - 1 || live[i] == 0 || root[i] == 0) return 0;
     const float4 rlo = box_lo[0], rhi = box_hi[0];
@@ -975,17 +975,33 @@ __device__ __forceinline__ int emit_wide_node(int i, const int2 *__restrict__ ra
     nd.b = make_uint4(w[4], w[5], w[6], w[7]);
     nd.c = make_uint4(w[8], w[9], w[10], w[11]);
     nd.d = make_uint4((unsigned)ref[0], (unsigned)ref[1], (unsigned)ref[2], (unsigned)ref[3]);
-    wnodes[wide_index(i, root, slot, pre4)] = nd;
+    const int at = wide_index(i, root, slot, pre4);
+    wnodes[at] = nd;
+    if (fnodes) {
+        // the float form: every plane as the value its 16-bit half decodes to (0x3f000000 | half << 8 = 1 + q / 32768)
+        BvhNode4F fn;
+        for (int k = 0; k < 4; k++) {
+            fn.lo_x[k] = __uint_as_float(0x3f000000u | (w[3 * k] & 0xffffu) << 8);
+            fn.hi_x[k] = __uint_as_float(0x3f000000u | (w[3 * k] >> 16) << 8);
+            fn.lo_y[k] = __uint_as_float(0x3f000000u | (w[3 * k + 1] & 0xffffu) << 8);
+            fn.hi_y[k] = __uint_as_float(0x3f000000u | (w[3 * k + 1] >> 16) << 8);
+            fn.lo_z[k] = __uint_as_float(0x3f000000u | (w[3 * k + 2] & 0xffffu) << 8);
+            fn.hi_z[k] = __uint_as_float(0x3f000000u | (w[3 * k + 2] >> 16) << 8);
+            fn.ref[k] = ref[k];
+            fn.pad[k] = 0;
+        }
+        fnodes[at] = fn;
+    }
     return root[i];
 }
 
 __global__ void k_emit_wide(const int2 *__restrict__ range, const int *__restrict__ live, const int *__restrict__ root,
                             const int4 *__restrict__ wkids, int n, int leaf_max, const float4 *__restrict__ box_lo,
                             const float4 *__restrict__ box_hi, const int *__restrict__ leafpos, const int *__restrict__ pre4,
-                            const int *__restrict__ slot, BvhNode4 *wnodes, int *wide_depth)
+                            const int *__restrict__ slot, BvhNode4 *wnodes, BvhNode4F *fnodes, int *wide_depth)
 {
     int d = emit_wide_node(blockIdx.x * blockDim.x + threadIdx.x, range, live, root, wkids, n, leaf_max, box_lo, box_hi, leafpos, pre4,
-                           slot, wnodes);
+                           slot, wnodes, fnodes);
     for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
     if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(wide_depth, d);
 }
@@ -1108,6 +1124,7 @@ void lbvh_free(LbvhResult *r)
 {
     if (r->nodes) (void)hipFree(r->nodes);
     if (r->wnodes) (void)hipFree(r->wnodes);
+    if (r->fnodes) (void)hipFree(r->fnodes);
     if (r->bvh_tri) (void)hipFree(r->bvh_tri);
     delete r->topo;
     *r = LbvhResult();
@@ -1731,6 +1748,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     A(scan_u64.alloc((size_t)blocks_for(n, 4096) + 1));
     A(hipMalloc((void **)&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
     A(hipMalloc((void **)&out->wnodes, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES)));
+    A(hipMalloc((void **)&out->fnodes, sizeof(BvhNode4F) * ((size_t)(n - 1) + WIDE_TOP_NODES)));
     A(hipMalloc((void **)&out->bvh_tri, sizeof(float4) * 3 * (size_t)n));
     if (e != hipSuccess) {
         if (err) *err = std::string("lbvh_build allocation: ") + hipGetErrorString(e);
@@ -1826,6 +1844,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
     RT_HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4 * sizeof(int), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->nodes, 0, sizeof(BvhNode) * (size_t)(n - 1), stream), err);
     RT_HIP_CHECK(hipMemsetAsync(out->wnodes, 0, sizeof(BvhNode4) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
+    RT_HIP_CHECK(hipMemsetAsync(out->fnodes, 0, sizeof(BvhNode4F) * ((size_t)(n - 1) + WIDE_TOP_NODES), stream), err);
     const bool ploc = builder != 1 && !sah;
     int max_depth = 0;
     DevBuf<int> cid[2], nn, size, offset, leafpos, order;
@@ -1933,7 +1952,7 @@ int lbvh_build_impl(const float4 *tri_mt, int n_tris, int leaf_max, int builder,
         hipLaunchKernelGGL(k_wide_slots, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, range.p, live.p, root.p, wkids.p, n, leaf_max,
                            wl, slot.p);
     hipLaunchKernelGGL(k_emit_wide, dim3(blocks_for(n - 1, B)), dim3(B), 0, stream, range.p, live.p, root.p, wkids.p, n, leaf_max,
-                       box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, slot.p, out->wnodes, scalars.p + 2);
+                       box_lo.p, box_hi.p, ploc ? leafpos.p : (const int *)nullptr, pre4.p, slot.p, out->wnodes, out->fnodes, scalars.p + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, ref_tri.p, vals[cur].p, ploc ? order.p : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);
@@ -2008,7 +2027,7 @@ int lbvh_refit(const float4 *tri_mt, int n_tris, hipStream_t stream, LbvhResult 
     hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, stream, t->children, t->range, t->parent, t->depth, n, out->leaf_max,
                        t->box_lo, t->box_hi, leafpos, t->pre, out->nodes, t->grid, t->scalars + 1);
     hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, stream, t->range, t->live, t->root, t->wkids, n, out->leaf_max, t->box_lo,
-                       t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, t->scalars + 2);
+                       t->box_hi, leafpos, t->pre4, t->slot, out->wnodes, out->fnodes, t->scalars + 2);
     hipLaunchKernelGGL(k_gather_tris, dim3(G), dim3(B), 0, stream, tri_mt, t->ref_tri, t->vals, t->ploc ? t->order : (const int *)nullptr, n,
                        out->bvh_tri);
     RT_HIP_CHECK(hipGetLastError(), err);

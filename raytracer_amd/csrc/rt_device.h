@@ -86,13 +86,17 @@ __device__ __forceinline__ bool tri_raycast(F3 v1, F3 e1, F3 e2, F3 o, F3 d, flo
 #define RT_GUARD 0
 #endif
 #if RT_GUARD
-__device__ __forceinline__ unsigned long long rt_guard(unsigned long long i, unsigned long long limit, FrameCounters *c)
+__device__ __forceinline__ unsigned long long rt_guard(unsigned long long i, unsigned long long limit, FrameCounters *c, unsigned int line)
 {
     if (i < limit) return i;
-    atomicAdd(&c->guard_hits, 1u);
+    if (atomicAdd(&c->guard_hits, 1u) == 0u) {      // the first one caught says where to look
+        c->guard_line = line;
+        c->guard_value = i;
+        c->guard_limit = limit;
+    }
     return 0ull;
 }
-#define RTG(i, limit) rt_guard((unsigned long long)(i), (unsigned long long)(limit), A.counters)
+#define RTG(i, limit) rt_guard((unsigned long long)(i), (unsigned long long)(limit), A.counters, (unsigned int)__LINE__)
 #else
 #define RTG(i, limit) (i)
 #endif

@@ -52,6 +52,16 @@ struct BvhNode4 {
     uint4 d;      // child references 0..3 (inner: wide node index; negative: leaf, as in BvhNode)
 };
 
+// The same four children as floats, 128 B, for the packet kernel: a wave that walks one node for all its rays loads
+// it through the scalar cache straight into scalar registers, where nothing is left to decode.  Every plane holds
+// f = 1 + q / 32768 of its lattice coordinate q, the value the packed node's 16-bit halves decode to, so both
+// node forms give bit-identical box tests with the same per-ray constants (slab_ray).
+struct BvhNode4F {
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+    int ref[4];
+    int pad[4];
+};
+
 // The first WIDE_TOP_NODES entries of the wide node array are the top WIDE_TOP_LEVELS levels as a complete
 // 4-ary tree (unused slots zero); the traversal kernel copies them into LDS.
 constexpr int WIDE_TOP_LEVELS = 4;
@@ -72,6 +82,7 @@ struct DevScene {
     const DevMaterial *mats;       // [n_mats]
     const BvhNode *nodes;          // LBVH, root = 0
     const BvhNode4 *wnodes;        // the tree collapsed to four children per node
+    const BvhNode4F *fnodes;       // the same nodes with float planes (same indices)
     QuantGrid grid;
     const float4 *bvh_tri;         // [n_tris*3] Morton order: (v1, original tri index bits) (e1,·) (e2,·)
     int32_t n_analytic, n_lights, n_tris, accel;
@@ -94,7 +105,15 @@ struct FrameCounters {
     unsigned long long node_idle, node_leafwait;   // lanes that sat out the node steps: without a ray / waiting at a leaf
     unsigned long long step_hist[16];             // rays by traversal steps taken: bin = bit length of the step count
     unsigned int max_steps, pad_steps;
-    unsigned int guard_hits, pad_guard;          // RT_GUARD builds: indices found outside their array (0 otherwise)
+    unsigned int guard_hits, guard_line;         // RT_GUARD builds: indices found outside their array (0 otherwise); source line of one of them
+    // RT_OPT_COUNT_TESTS only.  box_slots: box tests on child slots that hold a child (box_tests charges four per node
+    // step).  coh[kind][bin][k]: how alike the lanes of a wave are during the node steps, by ray kind (0 camera,
+    // 1 shadow, 2 reflection) and by the ray's own node-step index (bin 15 = fifteenth step and later): k = 0 lanes at a
+    // node, 1 the sum over those lanes of how many lanes of the wave (same kind) stand at the SAME node, 2 lanes
+    // at the node the first such lane holds, 3 lanes whose direction-sign octant is the first such lane's.
+    unsigned long long box_slots;
+    unsigned long long coh[3][16][4];
+    unsigned long long guard_value, guard_limit; // RT_GUARD builds: the index caught at guard_line and the size of its array
 };
 
 // ------------------------------------------------------------------ host-side state
@@ -105,6 +124,7 @@ struct LbvhResult {
     LbvhTopology *topo = nullptr;
     BvhNode *nodes = nullptr;      // [max(n_tris-1,1)]
     BvhNode4 *wnodes = nullptr;    // [WIDE_TOP_NODES + max(n_tris-1,1)] (about a quarter used)
+    BvhNode4F *fnodes = nullptr;   // same entries, float planes
     QuantGrid grid = {};
     float4 *bvh_tri = nullptr;     // [n_tris*3]
     int n_nodes = 0, depth = 0, wide_depth = 0, leaf_max = 0, builder = 0;

@@ -310,6 +310,13 @@ int ensure_accel(rt_ctx *c, int *accel)
     bool want = c->opt_accel == 2 || (c->opt_accel == 0 && c->n_tris > RT_BRUTE_MAX);
     if (c->n_tris < 2) want = false;
     if (want && (!c->bvh.nodes || c->bvh.leaf_max != c->opt_leaf_max || c->bvh.builder != c->opt_builder || c->bvh.split != split_cells(c))) {
+        // A rebuild frees the nodes and triangle copy that frames of other slots may still be reading, and a captured
+        // graph holds their addresses: wait for every slot and drop the graphs first, as the scene-changing calls do.
+        if (c->bvh.nodes) {
+            quiesce(c);
+            drop_graphs(c);
+            c->state_version++;
+        }
         std::string err;
         int rc = lbvh_build(c->d_tri_mt, c->n_tris, c->opt_leaf_max, c->opt_builder, split_cells(c), c->stream, &c->bvh, &err);
         if (rc != RT_OK) return fail(rc, err);
@@ -354,9 +361,10 @@ int validate_rows(int W, int H, const rt_rowset *r)
 DevScene device_scene(const rt_ctx *c, int accel)
 {
     DevScene sc;
+    memset(&sc, 0, sizeof sc);      // padding included: the struct is compared bytewise as part of the captured graph's key
     sc.analytic = c->d_analytic; sc.lights = c->d_lights;
     sc.tri_mt = c->d_tri_mt; sc.tri_n = c->d_tri_n; sc.tri_vn = c->d_tri_vn; sc.tri_vt = c->d_tri_vt; sc.mats = c->d_mats;
-    sc.nodes = c->bvh.nodes; sc.wnodes = c->bvh.wnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
+    sc.nodes = c->bvh.nodes; sc.wnodes = c->bvh.wnodes; sc.fnodes = c->bvh.fnodes; sc.grid = c->bvh.grid; sc.bvh_tri = c->bvh.bvh_tri;
     sc.n_analytic = c->n_analytic; sc.n_lights = c->n_lights; sc.n_tris = c->n_tris; sc.accel = accel;
     sc.n_refs = c->bvh.n_refs;
     return sc;
@@ -386,6 +394,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     const DevScene sc = device_scene(c, accel);
 
     FrameParams fp;
+    memset(&fp, 0, sizeof fp);      // padding included, as for the scene
     fp.W = W; fp.H = H; fp.rows = *rows; fp.max_depth = max_depth;
     fp.count_tests = c->opt_count; fp.timing = c->opt_timing;
     fp.stack_depth = accel ? c->bvh.depth : 0;
@@ -411,7 +420,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
             FrameParams fp; DevScene sc; DevCamera cam; void *out[4]; void *ws[16]; unsigned long long version;
         } key;
         memset(&key, 0, sizeof key);
-        key.fp = fp; key.sc = sc; key.cam = c->cam;
+        memcpy(&key.fp, &fp, sizeof fp); memcpy(&key.sc, &sc, sizeof sc); key.cam = c->cam;
         key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
         void *wsp[16] = { c->f->ws.records, c->f->ws.queue_o[0], c->f->ws.queue_o[1], c->f->ws.queue_d[0], c->f->ws.queue_d[1], c->f->ws.counters,
                           c->f->ws.p_hits, c->f->ws.p_occ, c->f->ws.sq_o, nullptr, c->f->ws.trace_cursors, c->f->ws.overflow,
@@ -1056,7 +1065,9 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     if (hipMemcpy(&fc, c->f->last_counters ? c->f->last_counters : c->f->ws.counters, sizeof fc, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(RT_E_DEVICE, "read frame counters");
     if (fc.guard_hits)      // only a guarded build (-DRT_GUARD=1) ever counts these
-        return fail(RT_E_DEVICE, "guarded build: " + std::to_string(fc.guard_hits) + " out-of-range indices were caught in the last frame");
+        return fail(RT_E_DEVICE, "guarded build: " + std::to_string(fc.guard_hits) + " out-of-range indices were caught in the last frame (the first: index " +
+                                     std::to_string(fc.guard_value) + " of " + std::to_string(fc.guard_limit) + " at source line " + std::to_string(fc.guard_line) +
+                                     "; line 0 = a traversal loop ran into its iteration bound)");
     out->rays_primary = c->f->last_primary;
     out->rays_shadow = fc.rays_shadow;
     out->rays_reflect = fc.rays_reflect;
@@ -1069,6 +1080,26 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
                 (double)fc.node_leafwait / (double)fc.node_iters, fc.leaf_iters,
                 fc.leaf_iters ? (double)fc.leaf_lanes / (double)fc.leaf_iters : 0.0, fc.refill_events,
                 fc.refill_events ? (double)fc.refill_lanes / (double)fc.refill_events : 0.0);
+    if (c->opt_count && getenv("RT_WF_DEBUG") && fc.node_iters) {
+        // how alike the lanes of a wave are during the node steps (FrameCounters::coh)
+        static const char *kinds[3] = { "camera", "shadow", "reflection" };
+        fprintf(stderr, "[rt] box tests on occupied child slots: %llu of %llu charged\n", fc.box_slots, fc.box_tests);
+        for (int k = 0; k < 3; k++) {
+            unsigned long long tot[4] = { 0, 0, 0, 0 };
+            for (int b = 0; b < 16; b++)
+                for (int j = 0; j < 4; j++) tot[j] += fc.coh[k][b][j];
+            if (!tot[0]) continue;
+            fprintf(stderr, "[rt] coherence %-10s lane-steps %llu: lanes of the wave at the same node %.2f, at the first lane's node %.1f %%, in the first lane's octant %.1f %%\n",
+                    kinds[k], tot[0], (double)tot[1] / (double)tot[0], 100.0 * (double)tot[2] / (double)tot[0], 100.0 * (double)tot[3] / (double)tot[0]);
+            fprintf(stderr, "[rt]   by the ray's node-step index (share of lane-steps %% | same-node lanes | first lane's node %% | octant %%):\n");
+            for (int b = 0; b < 16; b++) {
+                const unsigned long long *q = fc.coh[k][b];
+                if (!q[0]) continue;
+                fprintf(stderr, "[rt]   %2d%s %5.1f | %5.2f | %5.1f | %5.1f\n", b, b == 15 ? "+" : " ", 100.0 * (double)q[0] / (double)tot[0],
+                        (double)q[1] / (double)q[0], 100.0 * (double)q[2] / (double)q[0], 100.0 * (double)q[3] / (double)q[0]);
+            }
+        }
+    }
     if (c->opt_count && getenv("RT_WF_DEBUG") && fc.max_steps) {
         fprintf(stderr, "[rt] steps per ray: max %u; rays by bit length of the step count:", fc.max_steps);
         for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", fc.step_hist[k]);

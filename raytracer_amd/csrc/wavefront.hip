@@ -64,6 +64,12 @@ constexpr unsigned SENT_U = 0x7fffffffu;  // NODE_SENTINEL as unsigned: "(unsign
 #ifndef WF_MERGE
 #define WF_MERGE 1         // trace level k's shadow rays and level k+1's nearest-hit rays in one launch
 #endif
+#ifndef WF_SETASIDE
+#define WF_SETASIDE 0      // 1: a shadow lane that reaches a leaf during node steps keeps it in a register and walks on (see the node step)
+#endif
+#ifndef WF_SETASIDE_VOTE
+#define WF_SETASIDE_VOTE 0 // 1: lanes that hold a set-aside leaf also vote for the leaf step
+#endif
 #ifndef WF_WAVES_EU
 #define WF_WAVES_EU 8      // register budget and resident blocks per CU of k_trace
 #endif
@@ -131,6 +137,18 @@ void k_trace(TraceArgs A)
     float best_t = FLT_MAX;
     Tally tl = { 0u, 0u, 0u };
     unsigned int dbg[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes, idle / leaf-waiting lanes at node steps
+    unsigned int box_slots = 0, nsteps = 0;                     // COUNT: box tests on occupied child slots; node steps of this lane's ray
+    __shared__ unsigned long long s_coh[COUNT ? 3 * 16 * 4 : 1];
+    if (COUNT) {
+        for (int k = threadIdx.x; k < 3 * 16 * 4; k += BLOCK) s_coh[k] = 0ull;
+        __syncthreads();
+    }
+#if WF_SETASIDE
+    int stash = 0;                     // a shadow lane's set-aside leaf reference (negative), 0 = none
+#endif
+#if RT_GUARD
+    unsigned int guard_iters = 0;      // guarded builds bound the loop: a slip in the lane state machine ends in an error, not a hang
+#endif
 
     // ---- per-wave fetch state (uniform): local range [cur, end) of queue positions in segment `seg`
     unsigned int cur = 0, end = 0;
@@ -167,6 +185,13 @@ void k_trace(TraceArgs A)
     };
 
     for (;;) {
+#if RT_GUARD
+        // Far beyond what a frame asks of one wave (the 1080p frame averages about a thousand iterations per wave).
+        if (++guard_iters > (1u << 22)) {
+            if (lane == 0) atomicAdd(&A.counters->guard_hits, 1u);
+            break;
+        }
+#endif
         // ---- refill idle lanes from the local range; claim a new unit when it is empty
         const unsigned long long idle = __ballot(node == NODE_SENTINEL);
         if (!exhausted && idle != 0ull && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
@@ -241,6 +266,10 @@ void k_trace(TraceArgs A)
                     sp = 1;
                     tri_left = 0;
                     node = 0;
+#if WF_SETASIDE
+                    stash = 0;
+#endif
+                    if (COUNT) nsteps = 0;
                 }
             }
             cur = min(end, cur + (unsigned)__popcll(idle));
@@ -254,10 +283,43 @@ void k_trace(TraceArgs A)
         }
 
         // the step more lanes are waiting for
+#if WF_SETASIDE && WF_SETASIDE_VOTE
+        const bool do_node = (int)__popcll(m_node) >= (int)__popcll(__ballot(node < 0 || stash != 0));
+#else
         const bool do_node = (int)__popcll(m_node) >= (int)__popcll(m_leaf);
+#endif
         const bool do_leaf = !do_node;
         if (COUNT && do_node) { dbg[0]++; dbg[1] += (unsigned)__popcll(m_node); dbg[6] += 64u - (unsigned)__popcll(m_node | m_leaf); dbg[7] += (unsigned)__popcll(m_leaf); }
         if (COUNT && do_leaf) { dbg[2]++; dbg[3] += (unsigned)__popcll(m_leaf); }
+        if (COUNT && do_node) {
+            // How alike are the lanes of this node step?  Per ray kind: the lanes at the same node as each lane, the
+            // lanes at the first lane's node, the lanes in the first lane's direction octant.
+            const bool at = (unsigned)node < SENT_U;
+            const int kind = PRIMARY ? 0 : ((MODE == 1 || (MODE == 2 && bit >= 0)) ? 1 : 2);
+            const int oct = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+            for (int kd = 0; kd < 3; kd++) {
+                const bool mine = at && kind == kd;
+                unsigned long long rest = __ballot(mine);
+                if (rest == 0ull) continue;
+                const int first = __ffsll(rest) - 1;
+                const int first_node = __shfl(node, first), first_oct = __shfl(oct, first);
+                unsigned int group = 0;
+                while (rest != 0ull) {
+                    const int nd = __shfl(node, __ffsll(rest) - 1);
+                    const unsigned long long g = __ballot(mine && node == nd);
+                    if (mine && node == nd) group = (unsigned)__popcll(g);
+                    rest &= ~g;
+                }
+                if (mine) {
+                    unsigned long long *c = s_coh + (kd * 16 + (int)min(nsteps, 15u)) * 4;
+                    atomicAdd(c, 1ull);
+                    atomicAdd(c + 1, (unsigned long long)group);
+                    if (node == first_node) atomicAdd(c + 2, 1ull);
+                    if (oct == first_oct) atomicAdd(c + 3, 1ull);
+                }
+            }
+            if (at) nsteps++;
+        }
         if (do_node) {
             // ---- inner-node step: four children per 64-byte node
             if ((unsigned)node < SENT_U) {
@@ -290,7 +352,11 @@ void k_trace(TraceArgs A)
                         dk[k] = __builtin_amdgcn_bitop3_b32(__float_as_int(nk), __float_as_int(fk - nk), (int)0x80000000, 0xF2);
                     }
                 }
-                if (COUNT) tl.box += 4;
+                if (COUNT) {
+                    tl.box += 4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) box_slots += rk[k] != NODE_SENTINEL ? 1u : 0u;
+                }
 #define WF_CSWAP(a, b)                                                          \
                 {                                                               \
                     const bool sw = dk[b] < dk[a];                              \
@@ -321,8 +387,64 @@ void k_trace(TraceArgs A)
                     if (dk[1] < 0) push(rk[1]);
                     node = rk[0];
                 }
+#if WF_SETASIDE
+                // Any-hit rays need no order (main.cpp:181-188 stops at the first primitive that accepts the ray,
+                // whichever it is).  A shadow lane that arrives at a leaf while the wave goes on with node steps
+                // therefore keeps the leaf in a register and takes the next node off its stack; the leaf is tested
+                // in the wave's next leaf step.  Only while the stack holds more than the end-of-ray mark; and when
+                // the mark comes off the stack with a leaf still set aside, that leaf becomes the lane's node and
+                // the mark goes back (stack[0] still holds it), so the ray ends only after the leaf was tested.
+                if (MODE == 1 || (MODE == 2 && bit >= 0)) {
+                    if (node == NODE_SENTINEL) {
+                        if (stash != 0) { node = stash; stash = 0; sp = 1; }
+                    } else if (node < 0 && stash == 0 && sp > 1) {
+                        stash = node;
+                        pop();
+                    }
+                }
+#endif
             }
         }
+#if WF_SETASIDE
+        if (do_leaf) {
+            // ---- leaf step with set-aside leaves: a lane tests the leaf it stands at, a shadow lane then the leaf it
+            // set aside (whether or not it stands at one); after the step no lane holds a set-aside leaf.
+            const bool shadow_lane = MODE == 1 || (MODE == 2 && bit >= 0);
+            const int at_leaf = node < 0 ? node : 0;
+            int ref = at_leaf != 0 ? at_leaf : stash, ref2 = at_leaf != 0 ? stash : 0;
+            stash = 0;
+            while (ref != 0) {
+                const int leaf = ~ref;
+                tri_i = leaf >> 3;
+                tri_left = (leaf & 7) + 1;
+                for (;;) {
+                    const float4 *tp = (const float4 *)((const char *)sc.bvh_tri + (unsigned)RTG(tri_i, sc.n_refs) * 48u);
+                    const float4 v1 = tp[0];
+                    const F3 e1 = f3(tp[1]), e2 = f3(tp[2]);
+                    float t;
+                    const bool h = tri_raycast(f3(v1), e1, e2, o, d, t);
+                    if (COUNT) tl.tri += 1;
+                    tri_i++;
+                    tri_left--;
+                    if (shadow_lane) {
+                        if (h) {                                       // main.cpp:183-186: any hit blocks the light
+                            atomicOr(&A.occ[RTG(slot, A.n_pix)], 1u << (RTG(bit, 32) & 31));
+                            node = NODE_SENTINEL;
+                            tri_left = 0;
+                            ref2 = 0;
+                        }
+                    } else if (h) {
+                        const int id = sc.n_analytic + __float_as_int(v1.w);
+                        if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
+                    }
+                    if (tri_left == 0) break;
+                }
+                ref = ref2;
+                ref2 = 0;
+            }
+            if (at_leaf != 0 && node != NODE_SENTINEL) pop();
+        }
+#else
         if (do_leaf) {
             // ---- leaf step: every triangle of the leaf through the reference's Moller-Trumbore test
             if (node < 0) {
@@ -356,6 +478,7 @@ void k_trace(TraceArgs A)
                 if (node != NODE_SENTINEL && tri_left == 0) pop();
             }
         }
+#endif
     }
 
     if ((COUNT || WF_TIMES) && A.wave_times && lane == 0) {
@@ -374,6 +497,189 @@ void k_trace(TraceArgs A)
             unsigned long long *dst = &A.counters->node_iters;
             for (int k = 0; k < 8; k++)
                 if (dbg[k]) atomicAdd(dst + k, (unsigned long long)dbg[k]);
+        }
+        {
+            unsigned long long v = box_slots;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters->box_slots, v);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * 16 * 4; k += BLOCK)
+            if (s_coh[k]) atomicAdd(&A.counters->coh[0][0][0] + k, s_coh[k]);
+    }
+}
+
+// ------------------------------------------------------------------ packet traversal of the camera rays
+// The 64 camera rays of an 8x8 pixel tile (main.cpp:262-272) start at one point and leave through neighbouring pixels:
+// during the node steps of k_trace most lanes of such a wave stand at the same node as their neighbours.  Here the
+// wave walks the hierarchy ONCE for its 64 rays: one node at a time, wave-uniform; the node comes through the scalar
+// cache as floats (BvhNode4F) into scalar registers, every lane tests its own ray against the four boxes with scalar
+// operands (nothing to decode, no per-lane stack, no per-lane sort), a child is entered when ANY lane's ray enters it,
+// in the order of the first such lane's entry distances, and the stack is one vector register (lane k holds entry k).
+// A leaf's triangles come through the scalar cache too and every lane runs the reference's own test on them
+// (main.cpp:109-129).  The hierarchy only prunes and ties go to the lowest id explicitly, so the hits are those of
+// k_trace bit for bit; the box arithmetic is the same fused multiply-add on the same values.
+#ifndef WF_PACKET
+#define WF_PACKET 1
+#endif
+constexpr int PK_STACK = 64;
+typedef float PkF16 __attribute__((ext_vector_type(16)));
+typedef float PkF4 __attribute__((ext_vector_type(4)));
+// loads through the constant address space with a wave-uniform address: scalar loads (s_load_dwordx16 / x4)
+typedef const __attribute__((address_space(4))) PkF16 *ConstF16P;
+typedef const __attribute__((address_space(4))) PkF4 *ConstF4P;
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_packet(TraceArgs A)
+{
+    static_assert(UNIT <= 64, "a packet is one wave");
+    const int lane = threadIdx.x & 63;
+    const DevScene &sc = A.sc;
+    Tally tl = { 0u, 0u, 0u };
+    unsigned int box_slots = 0, n_node_steps = 0, n_node_lanes = 0, n_leaf_steps = 0, n_leaf_lanes = 0;
+    const int n_shards = (int)min((unsigned)SHARDS, gridDim.x);
+    const int max_probes = min(MAX_PROBES, n_shards);
+    int shard = (int)(blockIdx.x % (unsigned)n_shards), probes = 0;
+    const unsigned int n_units = (unsigned)A.n_regions * UPR;
+#if RT_GUARD
+    unsigned int guard_iters = 0;
+#endif
+    while (n_units != 0) {
+        // ---- claim one unit of 64 slots = one 8x8 pixel tile (same cursors and stealing as k_trace)
+        unsigned int k = 0;
+        if (lane == 0) k = atomicAdd(&A.cursors[shard * CURSOR_STRIDE], 1u);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        const unsigned long long unit = (unsigned long long)k * (unsigned)n_shards + (unsigned)shard;
+        if (unit >= n_units) {
+            shard = shard + 1 == n_shards ? 0 : shard + 1;
+            if (++probes >= max_probes) break;
+            continue;
+        }
+        const unsigned int u = (unsigned)unit, region = u / UPR, sub = u % UPR, r0 = region * REGION;
+        const unsigned int cnt = A.n_slots > r0 ? min((unsigned)REGION, A.n_slots - r0) : 0u;
+        const unsigned int cur = r0 + sub * UNIT, end = r0 + min(sub * UNIT + UNIT, cnt);
+        if (cur >= end) continue;
+        const unsigned int my = cur + (unsigned)lane;
+        bool live = my < end;
+        const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, live ? my : cur);
+        live = live && pr.live;
+        const F3 o = pr.o, d = pr.d;
+        float best_t = FLT_MAX;
+        int best_id = -1;
+        if (live) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+        F3 inv, oi;
+        uint3 sel_n, sel_f;
+        slab_ray(sc.grid, o, d, inv, oi, sel_n, sel_f);
+        const unsigned long long alive = __ballot(live);
+        if (alive == 0ull) continue;
+        // When every ray of the tile points into the same octant, near and far planes are picked once per wave.
+        const unsigned long long mx = __ballot(live && inv.x < 0.0f), my_ = __ballot(live && inv.y < 0.0f), mz = __ballot(live && inv.z < 0.0f);
+        const bool uni = (mx == 0ull || mx == alive) && (my_ == 0ull || my_ == alive) && (mz == 0ull || mz == alive);
+        const bool sx = mx != 0ull, sy = my_ != 0ull, sz = mz != 0ull;
+
+        int stackv = 0;          // the packet's stack: lane k holds entry k
+        int sp = 0, node = 0;    // wave-uniform
+        for (;;) {
+#if RT_GUARD
+            if (++guard_iters > (1u << 22)) {
+                if (lane == 0) atomicAdd(&A.counters->guard_hits, 1u);
+                break;
+            }
+#endif
+            if (node >= 0) {
+                // BvhNode4F through the scalar cache: lo_x hi_x lo_y hi_y lo_z hi_z ref (pad is not read)
+                ConstF4P np = (ConstF4P)(unsigned long long)(sc.fnodes + (unsigned)RTG(node, A.n_wnodes));
+                const PkF4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], rf = np[6];
+                unsigned int key[4];
+                const int ref[4] = { __float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w) };
+                float tn[4], tf[4];
+                if (uni) {
+                    // the planes every ray meets first / last, picked once for the wave
+                    const PkF4 ax = sx ? hx : lx, bx = sx ? lx : hx, ay = sy ? hy : ly, by = sy ? ly : hy, az = sz ? hz : lz, bz = sz ? lz : hz;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        tn[c] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ax[c], inv.x, oi.x), __builtin_fmaf(ay[c], inv.y, oi.y)),
+                                                      __builtin_fmaf(az[c], inv.z, oi.z)), 0.0f);
+                        tf[c] = fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(bx[c], inv.x, oi.x), __builtin_fmaf(by[c], inv.y, oi.y)),
+                                                      __builtin_fmaf(bz[c], inv.z, oi.z)), best_t);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float x0 = __builtin_fmaf(lx[c], inv.x, oi.x), x1 = __builtin_fmaf(hx[c], inv.x, oi.x);
+                        const float y0 = __builtin_fmaf(ly[c], inv.y, oi.y), y1 = __builtin_fmaf(hy[c], inv.y, oi.y);
+                        const float z0 = __builtin_fmaf(lz[c], inv.z, oi.z), z1 = __builtin_fmaf(hz[c], inv.z, oi.z);
+                        tn[c] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)), 0.0f);
+                        tf[c] = fminf(__builtin_fminf(__builtin_fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)), best_t);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    // an unused slot is never entered (its inverted box only says so while near and far planes are
+                    // picked by the direction signs; the minimum / maximum form above would turn it round)
+                    const unsigned long long m = ref[c] == NODE_SENTINEL ? 0ull : (__ballot(tn[c] <= tf[c]) & alive);
+                    key[c] = 0xffffffffu;
+                    if (m != 0ull) key[c] = (unsigned)__builtin_amdgcn_readlane(__float_as_int(tn[c]), __ffsll((long long)m) - 1);
+                    if (COUNT) box_slots += (live && ref[c] != NODE_SENTINEL) ? 1u : 0u;
+                }
+                if (COUNT) { tl.box += live ? 4u : 0u; n_node_steps++; n_node_lanes += (unsigned)__popcll(alive); }
+                // children by the first entering lane's entry distance (non-negative floats order like their bits); all scalar
+#define PK_CSWAP(a, b)                                                          \
+                if (key[b] < key[a]) {                                          \
+                    const unsigned int tk = key[a]; key[a] = key[b]; key[b] = tk; \
+                    const int tr = ref_[a]; ref_[a] = ref_[b]; ref_[b] = tr;    \
+                }
+                int ref_[4] = { ref[0], ref[1], ref[2], ref[3] };
+                PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
+#undef PK_CSWAP
+                if (key[0] == 0xffffffffu) {
+                    if (sp == 0) break;
+                    sp--;
+                    node = __builtin_amdgcn_readlane(stackv, sp);
+                } else {
+                    // farthest first, so that the nearest of them comes off first
+#pragma unroll
+                    for (int c = 3; c >= 1; c--)
+                        if (key[c] != 0xffffffffu) {
+                            if (lane == (int)RTG(sp, PK_STACK)) stackv = ref_[c];
+                            sp++;
+                        }
+                    node = ref_[0];
+                }
+            } else {
+                // ---- leaf: every triangle through the reference's test, for every ray of the tile
+                const int leaf = ~node;
+                int ti = leaf >> 3;
+                const int n_t = (leaf & 7) + 1;
+                for (int j = 0; j < n_t; j++, ti++) {
+                    ConstF4P tp = (ConstF4P)(unsigned long long)((const char *)sc.bvh_tri + (unsigned)RTG(ti, sc.n_refs) * 48u);
+                    const PkF4 v1 = tp[0], e1 = tp[1], e2 = tp[2];
+                    float t;
+                    if (live && tri_raycast(mk(v1.x, v1.y, v1.z), mk(e1.x, e1.y, e1.z), mk(e2.x, e2.y, e2.z), o, d, t)) {
+                        const int id = sc.n_analytic + __float_as_int(v1.w);
+                        if (best_t > t || (best_t == t && id < best_id)) { best_t = t; best_id = id; }
+                    }
+                    if (COUNT && live) tl.tri += 1;
+                }
+                if (COUNT) { n_leaf_steps++; n_leaf_lanes += (unsigned)__popcll(alive); }
+                if (sp == 0) break;
+                sp--;
+                node = __builtin_amdgcn_readlane(stackv, sp);
+            }
+        }
+        if (live) A.hits[RTG((unsigned)pr.pixel, A.n_pix)] = make_float2(best_t, __int_as_float(best_id));
+    }
+    if (COUNT) {
+        unsigned int vals[4] = { tl.box, tl.tri, tl.analytic, box_slots };
+        for (int c = 0; c < 4; c++) {
+            unsigned long long v = vals[c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v)
+                atomicAdd(c == 0 ? &A.counters->box_tests : c == 1 ? &A.counters->tri_tests : c == 2 ? &A.counters->analytic_tests : &A.counters->box_slots, v);
+        }
+        if (lane == 0) {
+            if (n_node_steps) { atomicAdd(&A.counters->node_iters, (unsigned long long)n_node_steps); atomicAdd(&A.counters->node_lanes, (unsigned long long)n_node_lanes); }
+            if (n_leaf_steps) { atomicAdd(&A.counters->leaf_iters, (unsigned long long)n_leaf_steps); atomicAdd(&A.counters->leaf_lanes, (unsigned long long)n_leaf_lanes); }
         }
     }
 }
@@ -617,6 +923,9 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     // run, and neither needs the other: they share one traversal launch (WF_MERGE), so a frame of D
     // bounces has D + 2 traversal drains instead of 2 D + 2.
     const bool merge = WF_MERGE != 0;
+    // camera rays as wave packets (RT_WF_PACKET=0/1 overrides the build's default); the packet's stack is one register
+    static const int packet_opt = [] { const char *e = getenv("RT_WF_PACKET"); return e ? atoi(e) : WF_PACKET; }();
+    const bool packet = packet_opt != 0 && scene.fnodes && 3 * fp.wide_depth + 1 <= PK_STACK;
     auto launch_gen = [&](int level, int chunk) {
         s.level = level; s.chunk = chunk;
         s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
@@ -657,7 +966,12 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         t.wave_times = d_times ? d_times + tw_stride * tw_modes.size() : nullptr;
         tw_modes.push_back(mode);
         if (int rc = tstamp()) return rc;
-        if (primary) launch_trace<0, true>(t, count, grid, stream);
+        if (primary && packet) {
+            // one wave per 8x8 tile: 8 waves per SIMD fit (few vector registers, no LDS)
+            const int pgrid = num_cus * 8;
+            if (count) hipLaunchKernelGGL(k_trace_packet<true>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
+            else hipLaunchKernelGGL(k_trace_packet<false>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
+        } else if (primary) launch_trace<0, true>(t, count, grid, stream);
         else if (mode == 0) launch_trace<0, false>(t, count, grid, stream);
         else if (mode == 1) launch_trace<1, false>(t, count, grid, stream);
         else launch_trace<2, false>(t, count, grid, stream);
