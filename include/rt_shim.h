@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+/* 2: rt_stats grew (ms_traverse, bvh_sah_cost, bvh_refs, box_tests_occupied, staging_ms) and rt_get_stats_sized exists.
+ * A host checks rt_abi_version() == RT_ABI_VERSION once at start-up; rt_get_stats writes sizeof(rt_stats) bytes of THIS
+ * header's layout, so a host built against an older header must call rt_get_stats_sized with its own sizeof instead. */
+#define RT_ABI_VERSION 2
 
 enum {
     RT_OK = 0,
@@ -98,6 +101,12 @@ typedef struct {
     float bvh_sah_cost;    /* surface-area-heuristic cost of the hierarchy as built: (sum of inner-node areas + sum of leaf areas x
                               triangles in the leaf) / root area; lower is better, refits do not update it */
     int32_t bvh_refs;      /* triangle references under the hierarchy (> n_triangles when large triangles were cut, RT_OPT_SPLIT) */
+    /* -- fields below exist from RT_ABI_VERSION 2 on; new fields are only ever appended -- */
+    uint64_t box_tests_occupied;   /* with RT_OPT_COUNT_TESTS: the box tests that met a child slot holding a child (box_tests charges
+                                      all four slots of every node step; slots of nodes with two or three children hold nothing) */
+    float staging_ms;      /* rt_render_frame / rt_render_frame_planes: host time of the last call's device-to-host hand-over
+                              (pinned staging copy + copy into the caller's buffers), 0 for the device-buffer entry points */
+    int32_t reserved0;
 } rt_stats;
 
 enum {
@@ -183,6 +192,16 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 int rt_render_frame(rt_ctx *ctx, int W, int H, int y0, int y1, int max_depth,
                     uint8_t *rgb8, int32_t *hit_id, float *rgb32);
 
+/* Host memory for the frame that the device can write directly (pinned; no counterpart in the reference, which
+ * allocates its image with `new color[w*h]`, Raytracer/main.cpp:259, once, and keeps it).  An output pointer of
+ * rt_render_frame / rt_render_frame_planes that lies wholly inside such a buffer is filled by one device-to-host copy
+ * at bus rate; any other host pointer works too and is filled through the context's own pinned staging buffer plus
+ * one more host copy.  (Registering memory the caller allocated itself is not offered: the runtime's host registration
+ * is not available on every system this library runs on.)  NULL on failure (rt_last_error).  The buffer lives until
+ * rt_free_host_buffer or rt_destroy. */
+void *rt_alloc_host_buffer(rt_ctx *ctx, uint64_t bytes);
+int rt_free_host_buffer(rt_ctx *ctx, void *buffer);
+
 /* The same frame with two more planes for tooling (replaces nothing in the reference, which keeps only
  * the 8-bit colour, Raytracer/main.cpp:273): hit_t = the camera ray's nearest t (FLT_MAX on a miss,
  * main.cpp:147-156), normal = GetNormal at that hit (main.cpp:164; 0,0,0 on a miss), 3 floats per
@@ -244,6 +263,11 @@ int rt_deinterleave_bands(rt_ctx *ctx, const void *d_src, void *d_dst, int W, in
 
 /* Waits for the context's outstanding work and reports counters/timings of the last frame. */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* The same for a caller that may have been compiled against another version of this header (no counterpart in the
+ * reference): writes at most `size` bytes of rt_stats, i.e. the fields the caller's struct has; fields are only ever
+ * appended, so a prefix is always a valid older rt_stats.  RT_E_INVALID when size is 0 or not a multiple of 4. */
+int rt_get_stats_sized(rt_ctx *ctx, rt_stats *out, uint64_t size);
 
 /* Wait for everything the context has enqueued. */
 int rt_synchronize(rt_ctx *ctx);

@@ -30,8 +30,10 @@ ABI_SYMBOLS = (
     "rt_set_mesh", "rt_set_triangles", "rt_set_triangle_materials", "rt_set_camera", "rt_render_frame",
     "rt_render_rows_device", "rt_deinterleave_bands", "rt_get_stats", "rt_synchronize", "rt_render_frame_planes",
     "rt_update_triangles", "rt_update_mesh_vertices", "rt_set_triangle_normals", "rt_set_triangle_texcoords",
-    "rt_render_rows_device_noalloc", "rt_render_rows_device_slot",
+    "rt_render_rows_device_noalloc", "rt_render_rows_device_slot", "rt_get_stats_sized",
+    "rt_alloc_host_buffer", "rt_free_host_buffer",
 )
+ABI_VERSION = 2     # RT_ABI_VERSION of include/rt_shim.h this binding mirrors
 MAX_FRAME_SLOTS = 8
 NOALLOC_SCRATCH_BYTES = 64 << 20
 
@@ -82,7 +84,8 @@ class Stats(C.Structure):
                 ("n_launches", C.c_int32), ("n_analytic", C.c_int32), ("n_triangles", C.c_int32),
                 ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("bvh_leaf_max", C.c_int32),
                 ("accel", C.c_int32), ("ms_build", C.c_float), ("ms_traverse", C.c_float),
-                ("bvh_sah_cost", C.c_float), ("bvh_refs", C.c_int32)]
+                ("bvh_sah_cost", C.c_float), ("bvh_refs", C.c_int32),
+                ("box_tests_occupied", C.c_uint64), ("staging_ms", C.c_float), ("reserved0", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -180,6 +183,12 @@ def load_library():
     L.rt_render_rows_device_slot.argtypes = [vp, i32, i32, i32, C.POINTER(RowSet), i32, vp, vp, vp, vp, vp]
     L.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_get_stats_sized.argtypes = [vp, vp, C.c_uint64]
+    L.rt_alloc_host_buffer.restype = vp
+    L.rt_alloc_host_buffer.argtypes = [vp, C.c_uint64]
+    L.rt_free_host_buffer.argtypes = [vp, vp]
+    if L.rt_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} speaks ABI version {L.rt_abi_version()}, this binding {ABI_VERSION}: rebuild the library")
     L.rt_synchronize.argtypes = [vp]
     _lib = L
     return L
@@ -313,6 +322,24 @@ class Context:
     def deinterleave_bands(self, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part, bytes_per_pixel, stream=None):
         self._check(self.L.rt_deinterleave_bands(self._h, d_src, d_dst, W, H, band_rows, n_parts, rows_per_part,
                                                  bytes_per_pixel, stream))
+
+    def alloc_host_buffer(self, shape, dtype=np.uint8):
+        """rt_alloc_host_buffer as a numpy array: pinned memory the device writes frames into directly.  The array is a
+        view; it dies with free_host_buffer() or the context."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.rt_alloc_host_buffer(self._h, n)
+        if not p:
+            raise RtError(-3, self.L.rt_last_error().decode())
+        return np.frombuffer((C.c_ubyte * n).from_address(p), dtype=dtype).reshape(shape)
+
+    def free_host_buffer(self, array):
+        self._check(self.L.rt_free_host_buffer(self._h, array.ctypes.data))
+
+    def render_frame_into(self, W, H, rgb8, max_depth=3, y0=0, y1=None):
+        """rt_render_frame into a caller-owned uint8 array (rows [y0, y1) x W x 3), the reference's `image` (main.cpp:259)."""
+        y1 = H if y1 is None else y1
+        assert rgb8.dtype == np.uint8 and rgb8.flags["C_CONTIGUOUS"] and rgb8.size == (y1 - y0) * W * 3
+        self._check(self.L.rt_render_frame(self._h, W, H, y0, y1, max_depth, rgb8.ctypes.data, None, None))
 
     def synchronize(self):
         self._check(self.L.rt_synchronize(self._h))

@@ -97,8 +97,12 @@ __device__ __forceinline__ unsigned long long rt_guard(unsigned long long i, uns
     return 0ull;
 }
 #define RTG(i, limit) rt_guard((unsigned long long)(i), (unsigned long long)(limit), A.counters, (unsigned int)__LINE__)
+// something a normal build does silently although it would change the image (a traversal stack that is full drops the
+// far child): counted like a caught index, so rt_get_stats fails
+#define RT_GUARD_EVENT(counters, value, limit) (void)rt_guard((unsigned long long)(value), (unsigned long long)(limit), (counters), (unsigned int)__LINE__)
 #else
 #define RTG(i, limit) (i)
+#define RT_GUARD_EVENT(counters, value, limit) ((void)0)
 #endif
 
 struct Tally { unsigned box, tri, analytic; };

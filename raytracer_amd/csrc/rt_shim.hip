@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <new>
 
 #include <mutex>
@@ -63,6 +64,7 @@ struct FrameSlot {
     bool last_timed = false;                 // the last frame recorded its device events
     uint64_t last_primary = 0;
     FrameCounters *last_counters = nullptr;  // where the last frame counted its rays (the workspace, or the scratch array)
+    float last_staging_ms = 0.f;             // host time of the last frame's device-to-host hand-over (host-buffer entry points)
     // Renders are asynchronous and may run on a caller's stream: frame_done is recorded behind every enqueued
     // frame, and everything that rewrites what a frame reads (scene, hierarchy, workspace, the captured graph)
     // waits for it first.
@@ -70,6 +72,9 @@ struct FrameSlot {
     bool frame_pending = false;
     hipStream_t last_stream = nullptr;
 };
+
+constexpr int HOST_PIECES = 8;     // pieces a plane of a host hand-over is cut into (piece k+1 flies while piece k is copied on)
+constexpr int HOST_PLANES_MAX = 6; // planes of rt_frame_planes
 
 struct rt_ctx {
     int device = 0;
@@ -95,6 +100,14 @@ struct rt_ctx {
     int opt_graph = 1;                       // replay of an unchanged frame's launches (only with timing and test counting off)
     unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
     unsigned char *scratch_ptr = nullptr;    // this device's copy of the no-alloc scratch array (set by rt_create)
+    // Host hand-over of rt_render_frame / rt_render_frame_planes: a pinned staging buffer the device copies into at
+    // full PCIe rate, in pieces, each copied on into the caller's (pageable) buffer while the next piece is in flight.
+    // Buffers from rt_alloc_host_buffer are pinned themselves and written by the device directly.
+    unsigned char *h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    hipEvent_t h_events[HOST_PLANES_MAX * HOST_PIECES] = {};
+    struct PinnedRange { unsigned char *p; size_t bytes; };
+    std::vector<PinnedRange> pinned;
     // Frames in flight: every slot has a workspace, a captured graph and a completion event of its own, so frames of
     // different slots may run side by side on different streams; f is the slot of the frame at hand (and afterwards
     // of the last one, which rt_get_stats reports).
@@ -371,7 +384,8 @@ DevScene device_scene(const rt_ctx *c, int accel)
 }
 
 int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
-                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false, int slot = 0)
+                  void *d_rgb32, void *d_hit_t, hipStream_t stream, bool host_outputs, bool host_aov = false, int slot = 0,
+                  unsigned host_want = 7u /* host_outputs: bit 0 rgb8, 1 hit_id, 2 rgb32 */)
 {
     if (slot < 0 || slot >= RT_MAX_FRAME_SLOTS) return fail(RT_E_INVALID, "frame slot out of range");
     if (int rc = validate_rows(W, H, rows)) return rc;
@@ -402,7 +416,11 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     fp.pipeline = c->opt_pipeline;
     fp.d_normal = nullptr;
     fp.d_uv = nullptr;
-    if (host_outputs) { d_rgb8 = c->f->ws.out_rgb8; d_hit_id = c->f->ws.out_id; d_rgb32 = c->f->ws.out_rgb32; }
+    if (host_outputs) {     // only the planes the caller asked for are produced
+        d_rgb8 = (host_want & 1u) ? c->f->ws.out_rgb8 : nullptr;
+        d_hit_id = (host_want & 2u) ? c->f->ws.out_id : nullptr;
+        d_rgb32 = (host_want & 4u) ? c->f->ws.out_rgb32 : nullptr;
+    }
     if (host_aov) {
         if (!c->f->ws.out_normal || c->f->ws.out_cap < pixels) return fail(RT_E_STATE, "plane staging missing");
         d_hit_t = c->f->ws.hit_t;
@@ -468,6 +486,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     c->f->frame_pending = true;
     c->f->last_stream = stream;
     c->f->last_counters = c->f->ws.counters;
+    c->f->last_staging_ms = 0.f;
     c->f->last_timed = fp.timing != 0;
     c->f->frame_valid = true;
     c->f->last_levels = max_depth + 1;
@@ -475,6 +494,73 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     c->f->last_accel = accel;
     c->f->last_wavefront = wavefront;
     c->f->last_primary = pixels;
+    return RT_OK;
+}
+
+// One plane of a host hand-over.
+struct HostPlane { void *dst; const void *d_src; size_t bytes; };
+
+bool host_range_pinned(const rt_ctx *c, const void *p, size_t bytes)
+{
+    const unsigned char *q = (const unsigned char *)p;
+    for (const rt_ctx::PinnedRange &r : c->pinned)
+        if (q >= r.p && q + bytes <= r.p + r.bytes) return true;
+    return false;
+}
+
+// Device planes into the caller's host buffers, behind the frame on the context's stream; returns when they are there.
+// A plane inside a buffer of rt_alloc_host_buffer is written by the device directly.  Any other buffer is
+// pageable: a device copy into it would go through the runtime's own bounce buffer at a fraction of the bus rate, so
+// such a plane goes into the context's pinned staging buffer in HOST_PIECES pieces, an event behind each, and the host
+// copies piece k on into the caller's buffer while the later pieces are still in flight.
+int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_planes > HOST_PLANES_MAX) return fail(RT_E_INVALID, "too many planes in one hand-over");
+    size_t staged = 0;
+    for (int k = 0; k < n_planes; k++)
+        if (planes[k].dst && planes[k].bytes && !host_range_pinned(c, planes[k].dst, planes[k].bytes)) staged += (planes[k].bytes + 255) & ~(size_t)255;
+    if (staged > c->h_stage_cap) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        if (hipHostMalloc((void **)&c->h_stage, staged, hipHostMallocDefault) != hipSuccess)
+            return fail(RT_E_NOMEM, "pinned staging buffer for the host hand-over");
+        c->h_stage_cap = staged;
+    }
+    struct Piece { void *dst; const unsigned char *src; size_t bytes; hipEvent_t ev; } pieces[HOST_PLANES_MAX * HOST_PIECES];
+    int n_pieces = 0;
+    size_t base = 0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_planes && e == hipSuccess; k++) {
+        const HostPlane &pl = planes[k];
+        if (!pl.dst || !pl.bytes) continue;
+        if (host_range_pinned(c, pl.dst, pl.bytes)) {
+            e = hipMemcpyAsync(pl.dst, pl.d_src, pl.bytes, hipMemcpyDeviceToHost, c->stream);
+            continue;
+        }
+        // small planes go in one piece; pieces are multiples of 4 KiB
+        const int want = pl.bytes >= ((size_t)1 << 20) ? HOST_PIECES : 1;
+        const size_t step = ((pl.bytes + want - 1) / want + 4095) & ~(size_t)4095;
+        for (size_t off = 0; off < pl.bytes && e == hipSuccess; off += step) {
+            const size_t n = off + step <= pl.bytes ? step : pl.bytes - off;
+            hipEvent_t &ev = c->h_events[n_pieces];
+            if (!ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + base + off, (const unsigned char *)pl.d_src + off, n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
+            pieces[n_pieces++] = { (unsigned char *)pl.dst + off, c->h_stage + base + off, n, ev };
+        }
+        base += (pl.bytes + 255) & ~(size_t)255;
+    }
+    for (int q = 0; q < n_pieces && e == hipSuccess; q++) {
+        e = hipEventSynchronize(pieces[q].ev);
+        if (e == hipSuccess) memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);     // nothing of this call may still be writing the staging buffer
+        return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
+    }
+    c->f->last_staging_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
 
@@ -542,6 +628,10 @@ void rt_destroy(rt_ctx *c)
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (hipEvent_t ev : c->h_events)
+        if (ev) (void)hipEventDestroy(ev);
+    for (const rt_ctx::PinnedRange &r : c->pinned) (void)hipHostFree(r.p);
     for (FrameSlot &f : c->slots)
         if (f.frame_done) (void)hipEventDestroy(f.frame_done);
     (void)hipStreamDestroy(c->stream);
@@ -871,20 +961,14 @@ int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
     DeviceGuard g(c->device);
     rt_rowset rows = { y0, 1, 1, y1 - y0 };
-    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true);
+    const unsigned want = (rgb8 ? 1u : 0u) | (hit_id ? 2u : 0u) | (rgb32 ? 4u : 0u);
+    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true, false, 0, want);
     if (rc != RT_OK) return rc;
     const size_t pixels = (size_t)W * (size_t)(y1 - y0);
-    hipError_t e = hipSuccess;
-    if (pixels) {
-        if (rgb8) e = hipMemcpyAsync(rgb8, c->f->ws.out_rgb8, 3 * pixels, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && hit_id)
-            e = hipMemcpyAsync(hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && rgb32)
-            e = hipMemcpyAsync(rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels, hipMemcpyDeviceToHost, c->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
-    return RT_OK;
+    if (!pixels) return RT_OK;
+    const HostPlane planes[3] = { { rgb8, c->f->ws.out_rgb8, 3 * pixels }, { hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels },
+                                  { rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels } };
+    return hand_over(c, planes, 3);
 }
 
 int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, const rt_frame_planes *out)
@@ -893,22 +977,43 @@ int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_dept
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
     DeviceGuard g(c->device);
     rt_rowset rows = { y0, 1, 1, y1 - y0 };
-    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true, true);
+    const unsigned want = (out->rgb8 ? 1u : 0u) | (out->hit_id ? 2u : 0u) | (out->rgb32 ? 4u : 0u);
+    int rc = render_common(c, W, H, &rows, max_depth, nullptr, nullptr, nullptr, nullptr, c->stream, true, true, 0, want);
     if (rc != RT_OK) return rc;
     const size_t pixels = (size_t)W * (size_t)(y1 - y0);
-    hipError_t e = hipSuccess;
-    auto pull = [&](void *dst, const void *src, size_t bytes) {
-        if (e == hipSuccess && dst && pixels) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
-    };
-    pull(out->rgb8, c->f->ws.out_rgb8, 3 * pixels);
-    pull(out->hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels);
-    pull(out->rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels);
-    pull(out->hit_t, c->f->ws.hit_t, sizeof(float) * pixels);
-    pull(out->normal, c->f->ws.out_normal, sizeof(float) * 3 * pixels);
-    pull(out->uv, c->f->ws.out_uv, sizeof(float) * 2 * pixels);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return fail(RT_E_DEVICE, std::string("frame readback: ") + hipGetErrorString(e));
-    return RT_OK;
+    if (!pixels) return RT_OK;
+    const HostPlane planes[6] = { { out->rgb8, c->f->ws.out_rgb8, 3 * pixels }, { out->hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels },
+                                  { out->rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels }, { out->hit_t, c->f->ws.hit_t, sizeof(float) * pixels },
+                                  { out->normal, c->f->ws.out_normal, sizeof(float) * 3 * pixels }, { out->uv, c->f->ws.out_uv, sizeof(float) * 2 * pixels } };
+    return hand_over(c, planes, 6);
+}
+
+void *rt_alloc_host_buffer(rt_ctx *c, uint64_t bytes)
+{
+    if (!c || bytes == 0) { fail(RT_E_INVALID, "rt_alloc_host_buffer: null context or no bytes"); return nullptr; }
+    DeviceGuard g(c->device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        fail(RT_E_NOMEM, "rt_alloc_host_buffer: hipHostMalloc failed");
+        return nullptr;
+    }
+    c->pinned.push_back({ (unsigned char *)p, (size_t)bytes });
+    return p;
+}
+
+int rt_free_host_buffer(rt_ctx *c, void *buffer)
+{
+    if (!c || !buffer) return fail(RT_E_INVALID, "rt_free_host_buffer: null argument");
+    DeviceGuard g(c->device);
+    for (size_t k = 0; k < c->pinned.size(); k++)
+        if (c->pinned[k].p == (unsigned char *)buffer) {
+            quiesce(c);
+            (void)hipHostFree(buffer);
+            c->pinned.erase(c->pinned.begin() + (long)k);
+            return RT_OK;
+        }
+    return fail(RT_E_STATE, "rt_free_host_buffer: not a buffer of rt_alloc_host_buffer");
 }
 
 int rt_render_rows_device(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
@@ -1007,6 +1112,7 @@ int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows
         c->f->last_stream = s;
     }
     c->f->last_counters = ws.counters;
+    c->f->last_staging_ms = 0.f;
     c->f->last_timed = false;
     c->f->frame_valid = true;
     c->f->last_levels = max_depth + 1;
@@ -1045,6 +1151,17 @@ int rt_synchronize(rt_ctx *c)
     return RT_OK;
 }
 
+int rt_get_stats_sized(rt_ctx *c, rt_stats *out, uint64_t size)
+{
+    if (!c || !out) return fail(RT_E_INVALID, "null argument");
+    if (size == 0 || size % 4 != 0) return fail(RT_E_INVALID, "rt_get_stats_sized: size must be a positive multiple of 4");
+    rt_stats full;
+    const int rc = rt_get_stats(c, &full);
+    if (rc != RT_OK) return rc;
+    memcpy(out, &full, size < sizeof full ? (size_t)size : sizeof full);
+    return RT_OK;
+}
+
 int rt_get_stats(rt_ctx *c, rt_stats *out)
 {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
@@ -1072,6 +1189,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
     out->rays_shadow = fc.rays_shadow;
     out->rays_reflect = fc.rays_reflect;
     out->box_tests = fc.box_tests;
+    out->box_tests_occupied = fc.box_slots;
+    out->staging_ms = c->f->last_staging_ms;
     out->tri_tests = fc.tri_tests;
     out->analytic_tests = fc.analytic_tests;
     if (c->opt_count && getenv("RT_WF_DEBUG") && fc.node_iters)

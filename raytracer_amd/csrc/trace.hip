@@ -21,6 +21,7 @@
 // Float discipline: no contraction, IEEE divide/sqrt, operand order as in maths.h,
 // so every value except powf is bit-equal to the reference's x86 results.
 #include "rt_device.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ void brute_nearest(const DevScene &sc, F3 o, F3 d, fl
 // stack: this lane's column of the block's LDS stack, element k at stack[k*BLOCK].
 template <bool COUNT>
 __device__ __forceinline__ void bvh_nearest(const DevScene &sc, F3 o, F3 d, bool live, float &best_t, int &best_id,
-                                            int *stack, int stack_cap, Tally &tl)
+                                            int *stack, int stack_cap, Tally &tl, FrameCounters *counters)
 {
     F3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 1;
@@ -57,7 +58,9 @@ __device__ __forceinline__ void bvh_nearest(const DevScene &sc, F3 o, F3 d, bool
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
                 int nearc = swap ? ch.y : ch.x, farc = swap ? ch.x : ch.y;
+                // The host sizes the stack from the tree's depth, so this never drops a child; a guarded build says so if it does.
                 if (sp < stack_cap) { stack[sp * BLOCK] = farc; sp++; }
+                else RT_GUARD_EVENT(counters, sp, stack_cap);
                 node = nearc;
                 continue;
             }
@@ -96,7 +99,8 @@ __device__ __forceinline__ bool brute_occluded(const DevScene &sc, F3 o, F3 d, T
 }
 
 template <bool COUNT>
-__device__ __forceinline__ bool bvh_occluded(const DevScene &sc, F3 o, F3 d, bool live, int *stack, int stack_cap, Tally &tl)
+__device__ __forceinline__ bool bvh_occluded(const DevScene &sc, F3 o, F3 d, bool live, int *stack, int stack_cap, Tally &tl,
+                                             FrameCounters *counters)
 {
     F3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 1;
@@ -114,6 +118,7 @@ __device__ __forceinline__ bool bvh_occluded(const DevScene &sc, F3 o, F3 d, boo
             if (COUNT) tl.box += 2;
             if (h0 && h1) {
                 if (sp < stack_cap) { stack[sp * BLOCK] = ch.y; sp++; }
+                else RT_GUARD_EVENT(counters, sp, stack_cap);
                 node = ch.x;
                 continue;
             }
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
         int best_id = -1;
         if (live) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
         if (ACCEL == 1) {
-            bvh_nearest<COUNT>(sc, o, d, live, best_t, best_id, stack, stack_cap, tl);
+            bvh_nearest<COUNT>(sc, o, d, live, best_t, best_id, stack, stack_cap, tl, A.counters);
         } else if (live) {
             brute_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
         }
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs A)
             if (lit) occ = analytic_occluded<COUNT>(sc, so, L, tl);
             if (ACCEL == 1) {
                 bool go = lit && !occ;
-                if (bvh_occluded<COUNT>(sc, so, L, go, stack, stack_cap, tl)) occ = true;
+                if (bvh_occluded<COUNT>(sc, so, L, go, stack, stack_cap, tl, A.counters)) occ = true;
             } else if (lit && !occ) {
                 occ = brute_occluded<COUNT>(sc, so, L, tl);
             }
@@ -454,6 +459,10 @@ int trace_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &
     a.uv = fp.d_uv;
     a.counters = ws.counters;
     a.stack_cap = fp.stack_depth;
+#if RT_GUARD
+    // guarded builds only: a deliberately short stack, to show that a dropped child is reported
+    if (const char *e = getenv("RT_GUARD_STACK_CAP")) a.stack_cap = atoi(e) > 0 ? atoi(e) : a.stack_cap;
+#endif
 
     const bool timing = fp.timing != 0;
     size_t ev = 0;

@@ -1,0 +1,123 @@
+"""The host-buffer side of the boundary (rt_render_frame, the seam of Raytracer/main.cpp:259, 273, 281) and the
+versioned statistics call, through the C ABI on the GPU."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import atrium_spec, cube_spec, rt, to_product
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _device_frame(ctx, W, H, D):
+    import torch
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    hid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rgb32 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    ctx.render_rows_device(W, H, rt.RowSet(0, 1, 1, H), D, rgb8.data_ptr(), hid.data_ptr(), rgb32.data_ptr(), None,
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return rgb8.cpu().numpy(), hid.cpu().numpy(), rgb32.cpu().numpy()
+
+
+def test_host_frame_equals_the_device_frame_staged_pinned_and_in_part():
+    W, H, D = 1000, 562, 3          # > 1 MiB of 8-bit colour: the staged hand-over goes in pieces
+    with rt.Context(0) as ctx:
+        to_product(ctx, atrium_spec(detail=0.05))
+        ctx.set_camera(rt.Camera(origin=(0.0, -1.5, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4))
+        d8, did, d32 = _device_frame(ctx, W, H, D)
+        assert (did >= 0).mean() > 0.5
+        # all three planes through the pinned staging buffer
+        g = ctx.render_frame(W, H, max_depth=D)
+        assert np.array_equal(g["rgb8"], d8) and np.array_equal(g["hit_id"], did)
+        assert np.array_equal(g["rgb32"].view(np.uint32), d32.view(np.uint32))
+        assert ctx.stats()["staging_ms"] > 0.0
+        # the reference's call: the 8-bit image alone, into a buffer the caller keeps (main.cpp:259)
+        image = np.full((H, W, 3), 9, np.uint8)
+        ctx.render_frame_into(W, H, image, max_depth=D)
+        assert np.array_equal(image, d8)
+        # a buffer from the library (pinned): the device writes it directly
+        pinned = ctx.alloc_host_buffer((H, W, 3))
+        pinned[:] = 9
+        ctx.render_frame_into(W, H, pinned, max_depth=D)
+        assert np.array_equal(pinned, d8)
+        # a row range into the middle of that buffer (still inside it), the rest untouched
+        pinned[:] = 9
+        ctx.render_frame_into(W, H, pinned[100:228], max_depth=D, y0=100, y1=228)
+        assert np.array_equal(pinned[100:228], d8[100:228]) and (pinned[:100] == 9).all() and (pinned[228:] == 9).all()
+        ctx.free_host_buffer(pinned)
+        del pinned
+        with pytest.raises(rt.RtError):
+            ctx.free_host_buffer(image)
+        image[:] = 9
+        ctx.render_frame_into(W, H, image, max_depth=D)
+        assert np.array_equal(image, d8)
+        # the tooling planes come over the same way
+        p = ctx.render_frame_planes(W, H, max_depth=D)
+        assert np.array_equal(p["rgb8"], d8) and np.array_equal(p["hit_id"], did)
+        assert np.isfinite(p["normal"]).all() and (p["hit_t"][did >= 0] < 3e38).all()
+
+
+def test_stats_for_a_caller_built_against_an_older_header():
+    with rt.Context(0) as ctx:
+        to_product(ctx, cube_spec(mirror=False, mesh_reflect=0.5))
+        ctx.set_camera(rt.Camera(pitch=8.0 / 160))
+        ctx.set_option(rt.OPT_COUNT_TESTS, 1)
+        ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+        ctx.render_frame(160, 120, max_depth=2)
+        full = ctx.stats()
+        assert 0 < full["box_tests_occupied"] <= full["box_tests"]
+        # a version-1 host's struct ended behind bvh_refs: exactly that prefix is written, nothing behind it
+        old_size = rt.Stats.bvh_refs.offset + 4
+        buf = (C.c_ubyte * C.sizeof(rt.Stats))(*([0xAB] * C.sizeof(rt.Stats)))
+        assert ctx.L.rt_get_stats_sized(ctx._h, C.addressof(buf), old_size) == 0
+        got = rt.Stats.from_buffer_copy(buf)
+        assert got.rays_primary == full["rays_primary"] and got.bvh_refs == full["bvh_refs"] and got.box_tests == full["box_tests"]
+        assert bytes(buf[old_size:]) == b"\xab" * (C.sizeof(rt.Stats) - old_size)
+        # a larger struct than the library knows is filled as far as the library's goes
+        big = (C.c_ubyte * (C.sizeof(rt.Stats) + 16))(*([0xCD] * (C.sizeof(rt.Stats) + 16)))
+        assert ctx.L.rt_get_stats_sized(ctx._h, C.addressof(big), C.sizeof(rt.Stats) + 16) == 0
+        assert bytes(big[C.sizeof(rt.Stats):]) == b"\xcd" * 16
+        assert ctx.L.rt_get_stats_sized(ctx._h, C.addressof(buf), 0) == -1
+        assert ctx.L.rt_get_stats_sized(ctx._h, C.addressof(buf), 6) == -1
+
+
+GUARD_LIB = os.path.join(ROOT, "raytracer_amd", "variants", "guard.so")
+
+_DROPPED_PUSH = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+from common import atrium_spec, rt, to_product
+with rt.Context(0) as ctx:
+    ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_FUSED)
+    to_product(ctx, atrium_spec(detail=0.05))
+    ctx.set_camera(rt.Camera(origin=(0.0, -1.5, -6.0), pitch=8.0 / 320, off_x=-4.0, off_y=-3.4))
+    ctx.render_frame(320, 200, max_depth=2)
+    try:
+        ctx.stats()
+        print("NO ERROR")
+    except rt.RtError as e:
+        print("ERROR", e)
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(GUARD_LIB), reason="the guarded variant is not built")
+def test_guarded_build_reports_a_traversal_stack_that_dropped_a_child():
+    """The fused kernel drops the far child when its stack is full (the host sizes the stack from the tree, so it never
+    is).  A guarded build counts that; with the stack cut to one entry (RT_GUARD_STACK_CAP, read by guarded builds only)
+    rt_get_stats must fail, and with the real size it must not."""
+    def run(cap):
+        env = dict(os.environ, RT_AMD_LIB=GUARD_LIB)
+        env.pop("RT_GUARD_STACK_CAP", None)
+        if cap:
+            env["RT_GUARD_STACK_CAP"] = str(cap)
+        return subprocess.run([sys.executable, "-c", _DROPPED_PUSH % {"root": ROOT}], env=env, capture_output=True, text=True,
+                              timeout=300).stdout
+    assert "NO ERROR" in run(0)
+    out = run(1)
+    assert "ERROR" in out and "guarded build" in out and "NO ERROR" not in out

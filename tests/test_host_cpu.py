@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.rt_abi_version() == 1
+    assert L.rt_abi_version() == rt.ABI_VERSION == 2
+    version = int(re.search(r"#define RT_ABI_VERSION (\d+)", header).group(1))
+    assert version == rt.ABI_VERSION
 
 
 def test_struct_layouts_match_the_header():
@@ -32,7 +34,9 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(rt.Analytic) == 8 + 24 + 12 + 4
     assert ctypes.sizeof(rt.Camera) == 28
     assert ctypes.sizeof(rt.RowSet) == 16
-    assert ctypes.sizeof(rt.Stats) == 104  # 6 x u64 + 3 x f32 + 7 x i32 + 3 x f32 + 1 x i32
+    assert ctypes.sizeof(rt.Stats) == 120  # 6 x u64 + 3 x f32 + 7 x i32 + 3 x f32 + 1 x i32, then (ABI 2) u64 + f32 + i32
+    # the fields of ABI version 1 keep their offsets: fields are only ever appended
+    assert rt.Stats.bvh_refs.offset == 100 and rt.Stats.box_tests_occupied.offset == 104
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():
@@ -43,6 +47,10 @@ def test_null_context_is_rejected_without_touching_a_gpu():
     rs = rt.RowSet(0, 1, 1, 8)
     assert L.rt_render_rows_device_slot(None, 1, 8, 8, rs, 1, None, None, None, None, None) == -1
     assert L.rt_render_rows_device_noalloc(None, 8, 8, rs, 1, None, None, None, None, None) == -1
+    s = rt.Stats()
+    assert L.rt_get_stats_sized(None, ctypes.addressof(s), ctypes.sizeof(s)) == -1
+    assert not L.rt_alloc_host_buffer(None, 64)
+    assert L.rt_free_host_buffer(None, ctypes.addressof(s)) == -1
 
 
 def test_headers_are_plain_c(tmp_path):
