@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames a rank keeps in flight (one frame slot and stream each); 0 = 4 when the frame is partitioned and a rank's share is at most 1.5 M pixels, else 1")
+                    help="frames a rank keeps in flight (one frame slot and stream each); 0 = 4 for frames of at most 10 M pixels, else 1: "
+                         "decided by the FRAME, never by the rank count, so every --gpus N of one workload runs in the same mode")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (slices staged through host memory) is for rehearsing the partitioned job where RCCL cannot run")
     ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (rehearsal of N ranks on a one-GPU box; RCCL refuses that, use --backend gloo)")
@@ -71,8 +72,19 @@ def cpu_baseline(wl, threads):
     dt = time.perf_counter() - t0
     rays = r["counts"]["primary"] + r["counts"]["shadow"] + r["counts"]["reflect"]
     out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "host_cpus": os.cpu_count(),       # what the machine has; `cores` is the threads this figure used
            "sample": "one full %dx%d frame (%d rays) through the CPU restatement with its median-split BVH, "
                      "OpenMP over rows" % (wl.W, wl.H, rays), "seconds": dt}
+    # the same hierarchy port on ONE thread, like the reference's own single-threaded loop (main.cpp:262-277), on every
+    # fourth row and column
+    lat1 = 4
+    t0 = time.perf_counter()
+    r = sc.render(wl.W, wl.H, max_depth=wl.max_depth, cam=cam, use_bvh=True, threads=1, x_step=lat1, y_step=lat1, want=())
+    dt = time.perf_counter() - t0
+    rays = r["counts"]["primary"] + r["counts"]["shadow"] + r["counts"]["reflect"]
+    out["bvh_port_1core"] = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1,
+                             "sample": "every %dth row and column (%d rays), the CPU restatement with its BVH on one thread" % (lat1, rays),
+                             "seconds": dt}
     # The reference's own algorithm is a linear scan over all primitives: time it single-threaded
     # on a sparse lattice so the number stays bounded.
     lat = 96
@@ -118,6 +130,41 @@ def share_table(ctx, n_slots, wl, band_rows, torch, dev, steps=10):
     return out
 
 
+def host_frame_times(ctx, wl, steps):
+    """The drop-in call of the reference's seam (rt_render_frame: the frame lands in a HOST buffer, main.cpp:259, 273, 281),
+    8-bit colour only, ms per frame: into an ordinary (pageable) array through the pinned staging buffer, and into a
+    buffer from rt_alloc_host_buffer that the device writes directly.  Never the benchmark's value."""
+    out = {}
+    image = np.zeros((wl.H, wl.W, 3), np.uint8)
+    pinned = ctx.alloc_host_buffer((wl.H, wl.W, 3))
+    for name, buf in (("host_frame_ms", image), ("host_frame_pinned_ms", pinned)):
+        for _ in range(2):
+            ctx.render_frame_into(wl.W, wl.H, buf, max_depth=wl.max_depth)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.render_frame_into(wl.W, wl.H, buf, max_depth=wl.max_depth)
+        out[name] = (time.perf_counter() - t0) / steps * 1e3
+    out["host_frame_staging_ms"] = ctx.stats()["staging_ms"]
+    ctx.free_host_buffer(pinned)
+    return out
+
+
+def measured_valu(workload, world, resolution):
+    """Issue utilisation, mean active lanes and the FMA / MUL / ADD share of the traversal kernels from the committed
+    counter passes (profiles/valu_counters.json, written by profiles/summarize.py); like the traffic figure it is only
+    reported for exactly the kernel sources, workload and frame size it was measured on."""
+    from raytracer_amd.build import source_hash
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "valu_counters.json")))
+    except Exception:
+        return None, "none"
+    if rec.get("source_hash") != source_hash():
+        return None, "profiles/valu_counters.json is stale (measured on other kernel sources)"
+    if world != 1 or workload not in rec or rec[workload].get("resolution") != list(resolution):
+        return None, "profiles/valu_counters.json has no entry for this run"
+    return rec[workload].get("kernels"), "profiles/valu_counters.json (" + rec[workload].get("source", "") + ")"
+
+
 def measured_traffic(workload, world, resolution):
     """HBM-side bytes per frame of the traversal kernel from the committed counter passes
     (profiles/hbm_traffic.json, written by profiles/hbm_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
@@ -128,12 +175,12 @@ def measured_traffic(workload, world, resolution):
     try:
         rec = json.load(open(tpath))
     except Exception:
-        return None, "none"
+        return (None, None), "none"
     if rec.get("source_hash") != source_hash():
-        return None, "profiles/hbm_traffic.json is stale (measured on other kernel sources)"
+        return (None, None), "profiles/hbm_traffic.json is stale (measured on other kernel sources)"
     if world != 1 or workload not in rec or rec[workload].get("resolution") != list(resolution):
-        return None, "profiles/hbm_traffic.json has no entry for this run"
-    return rec[workload].get("bytes_per_frame"), "profiles/hbm_traffic.json (" + rec[workload].get("source", "") + ")"
+        return (None, None), "profiles/hbm_traffic.json has no entry for this run"
+    return (rec[workload].get("bytes_per_frame"), rec[workload].get("bytes_per_frame_as_counted")), "profiles/hbm_traffic.json (" + rec[workload].get("source", "") + ")"
 
 
 def main():
@@ -196,8 +243,10 @@ def main():
     # context, one stream and one buffer set each.  On one GPU the whole frame fills the chip and one slot is enough.
     # (Measured on one GPU, share of 1080p: whole frame +1.6 %, half 1.14x, quarter 1.43x, eighth 1.9x with four slots: a share
     # of more than ~1.5 M pixels fills the chip by itself and is not worth three more scene copies.)
-    share_pixels = wl.W * wl.H // world
-    in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (4 if world > 1 and share_pixels <= 1_500_000 else 1)
+    # The mode is decided by the frame, not by the rank count: a 1 -> 8 curve of one workload compares like with like
+    # (one whole 1080p frame gains 3.5 % from four slots, an eighth of it 1.9x).  `frame_latency_ms` and `single_frame_value`
+    # give the same job one frame at a time, at every rank count.
+    in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (4 if wl.W * wl.H <= 10_000_000 else 1)
     ctx = make_context()
     pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather, frames_in_flight=in_flight)
 
@@ -212,6 +261,7 @@ def main():
     ctx.set_option(rt.OPT_TIMING, 0)
     frame_latency_ms = None
     if in_flight == 1:
+        # (frame_latency_ms is then ms_per_step itself; filled in below)
         # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
         with torch.cuda.stream(pr.stream):
             for _ in range(a.warmup):
@@ -222,6 +272,7 @@ def main():
                 pr.render()
             sync_all()
             dt = time.perf_counter() - t0
+        frame_latency_ms = dt / a.steps * 1e3
     else:
         # Frames go to the slots round-robin; the consumer of a frame (here: nothing but the wait) runs in_flight - 1
         # frames behind the producer, as a display or an encoder would.
@@ -274,19 +325,31 @@ def main():
     sync_all()
     cst = ctx.stats()
     ctx.set_option(rt.OPT_COUNT_TESTS, 0)
-    flops = cst["box_tests"] * FLOP_BOX + cst["tri_tests"] * FLOP_TRI + cst["analytic_tests"] * FLOP_ANALYTIC
+    # Box tests are counted two ways: `box_tests` charges the four child slots of every node step (what the kernel
+    # executes: a slot that holds no child is tested like the others), `box_tests_occupied` only the slots that hold a
+    # child.  The fraction published as `frac` is the LOWER one, from the occupied slots; `frac_charged` is the other.
+    # (The camera rays go through the packet kernel, where every ray of a tile tests every node the tile visits.)
+    flops_charged = cst["box_tests"] * FLOP_BOX + cst["tri_tests"] * FLOP_TRI + cst["analytic_tests"] * FLOP_ANALYTIC
+    occupied = cst["box_tests_occupied"] or cst["box_tests"]      # the fused and linear-scan kernels have no empty slots to count
+    flops = occupied * FLOP_BOX + cst["tri_tests"] * FLOP_TRI + cst["analytic_tests"] * FLOP_ANALYTIC
     # k_trace (LBVH scenes: traversal alone, timed by its own device events) or k_bounce (small scenes)
     kernel_ms = st["ms_traverse"] if st["ms_traverse"] > 0 else st["ms_trace"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    traffic, traffic_source = measured_traffic(a.workload, world, (wl.W, wl.H))
+    achieved_charged = flops_charged / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    valu, valu_source = measured_valu(a.workload, world, (wl.W, wl.H))
+    (traffic, traffic_as_counted), traffic_source = measured_traffic(a.workload, world, (wl.W, wl.H))
     compulsory = wl.W * wl.H * 3 + wl.n_tris * (48 + 16) + st["bvh_nodes"] * 64
     roofline = {
         "bound": "valu_fp32",
         "kernel": ("k_trace (closest + any-hit, all %d levels of one frame)" if st["accel"] else
                    "k_bounce (all %d levels of one frame)") % (wl.max_depth + 1),
         "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-        "traffic": traffic, "traffic_source": traffic_source,
-        "flops_per_frame": flops, "box_tests": cst["box_tests"], "tri_tests": cst["tri_tests"],
+        # fabric-side bytes per frame of the traversal kernels: FETCH_SIZE doubled (the gfx950 correction, calibrated on wide
+        # streaming reads, not on this kernel's scattered 64-byte fetches) + WRITE_SIZE; and as the counters report them
+        "traffic": traffic, "traffic_as_counted": traffic_as_counted, "traffic_source": traffic_source,
+        "frac_charged": achieved_charged / PEAK_FP32_TFLOPS, "flops_per_frame_charged": flops_charged,
+        "valu": valu, "valu_source": valu_source,
+        "flops_per_frame": flops, "box_tests": cst["box_tests"], "box_tests_occupied": occupied, "tri_tests": cst["tri_tests"],
         "analytic_tests": cst["analytic_tests"], "kernel_ms_per_frame": kernel_ms,
         "all_bounce_stages_ms_per_frame": st["ms_trace"],
         "hbm": {"compulsory_bytes_per_frame": compulsory,
@@ -309,8 +372,10 @@ def main():
             "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
             "roofline": roofline,
         }
-        if frame_latency_ms is not None:
-            out["frame_latency_ms"] = frame_latency_ms      # one frame at a time; ms_per_step is the rate with frames in flight
+        # one frame at a time (what the reference's setup() does, main.cpp:262-277), at every rank count; ms_per_step and
+        # value are the rate with config.frames_in_flight frames in flight
+        out["frame_latency_ms"] = frame_latency_ms
+        out["single_frame_value"] = rays / frame_latency_ms / 1e3
         if world == 1 and not a.no_extras:
             # the same frames with every launch issued one by one (a frame that changes cannot replay a graph)
             ctx.set_option(rt.OPT_TIMING, 0)
@@ -318,6 +383,7 @@ def main():
             with torch.cuda.stream(pr.stream):
                 out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
             ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
+            out.update(host_frame_times(ctx, wl, min(a.steps, 10)))
             if st["accel"]:
                 out["share_ms"] = share_table(ctx, 1, wl, a.band_rows, torch, dev)
                 out["share_ms_4_in_flight"] = share_table(ctx, 4, wl, a.band_rows, torch, dev)

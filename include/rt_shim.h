@@ -104,8 +104,9 @@ typedef struct {
     /* -- fields below exist from RT_ABI_VERSION 2 on; new fields are only ever appended -- */
     uint64_t box_tests_occupied;   /* with RT_OPT_COUNT_TESTS: the box tests that met a child slot holding a child (box_tests charges
                                       all four slots of every node step; slots of nodes with two or three children hold nothing) */
-    float staging_ms;      /* rt_render_frame / rt_render_frame_planes: host time of the last call's device-to-host hand-over
-                              (pinned staging copy + copy into the caller's buffers), 0 for the device-buffer entry points */
+    float staging_ms;      /* rt_render_frame / rt_render_frame_planes: host time of the last call's device-to-host hand-over, from
+                              the moment the device finished the frame until the caller's buffers were filled (copies into the
+                              pinned staging buffer + host copies on into the caller's memory); 0 for the device-buffer entry points */
     int32_t reserved0;
 } rt_stats;
 

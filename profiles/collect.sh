@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box:
 #   profiles/collect.sh <tag> [bench args...]
+# One frame at a time (--frames-in-flight 1): with several in flight kernels of different frames overlap and the
+# profiler's durations are no longer a kernel's own.
 # Pass 0 is the kernel trace (+ --stats); every counter pass is its own run (PMC is never
 # combined with a trace domain other than the kernel trace).  Raw output goes to
 # gpurun_out/prof_<tag>/, summaries are written by profiles/summarize.py.
@@ -11,7 +13,7 @@ OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --frames-in-flight 1 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; exit 1; }
 i=0
 for PMC in \
@@ -25,4 +27,6 @@ do
   timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i failed"; tail -5 "$OUT/pmc$i.log"; exit 1; }
 done
 python3 "$R/profiles/summarize.py" "$OUT" > "$OUT/summary.txt" 2>&1
+echo "== derived (profiles/derive.py)" >> "$OUT/summary.txt"
+python3 "$R/profiles/derive.py" "$OUT" >> "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

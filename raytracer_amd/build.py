@@ -63,7 +63,9 @@ def source_hash():
 
 def build_lib(force=False, verbose=False, extra_flags=(), out=LIB):
     srcs, deps = _lib_deps()
-    if not force and _newer(out, deps):
+    # the up-to-date shortcut only knows the default flags of each output file: extra flags on the library's own
+    # path would otherwise return a stale build without them
+    if not force and _newer(out, deps) and not (extra_flags and out == LIB):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [_hipcc()] + HIP_FLAGS + list(extra_flags) + srcs + ["-o", out]
@@ -101,8 +103,11 @@ def build_host(force=False, verbose=False):
     if not force and _newer(HOST_BIN, srcs + hdrs + [LIB]):
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include")] + srcs + [
-        "-o", HOST_BIN, "-L", HERE, "-lrt_amd", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+    # multigpu.cpp calls the HIP runtime and RCCL directly (streams, buffers, the all-gather of the slices)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include")] + srcs + [
+        "-o", HOST_BIN, "-L", HERE, "-lrt_amd", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+        "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE, "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -348,8 +348,9 @@ void k_trace(TraceArgs A)
                                  z = plane_pair(wz[k], sel_n.z, sel_f.z, inv.z, oi.z);
                         const float nk = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), 0.0f);
                         const float fk = fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), tmax);
-                        // nk | (~(fk - nk) & sign): one v_bitop3_b32 (truth table 0xF2 = a | (~b & c))
-                        dk[k] = __builtin_amdgcn_bitop3_b32(__float_as_int(nk), __float_as_int(fk - nk), (int)0x80000000, 0xF2);
+                        // bit 31 from ~(fk - nk), bits 30..0 from nk: one v_bitop3_b32 (truth table 0x72 = c ? ~b : a).  nk's own
+                        // sign bit is dropped: max(.., 0.0f) may hand back -0.0f, which would read as a hit at the far end.
+                        dk[k] = __builtin_amdgcn_bitop3_b32(__float_as_int(nk), __float_as_int(fk - nk), (int)0x80000000, 0x72);
                     }
                 }
                 if (COUNT) {

@@ -8,7 +8,11 @@
 //             [--width W] [--height H] [--depth D] [--obj mesh.obj] [--mesh-reflect K]
 //             [--no-mirror] [--no-floor] [--device N] [--dump-obj mesh.obj]
 //             [--relaxed] [--exr frame.exr] [--frames N] [--wobble A] [--smooth] [--dump-obj-relaxed mesh.obj]
+//             [--gpus N] [--band-rows R]
 //
+// --gpus N renders every frame on GPUs device .. device+N-1 from this one process: one context per GPU with the
+// same scene, the rows dealt out in R-row bands round-robin, the 8-bit slices all-gathered with RCCL (multigpu.cpp);
+// 8-bit colour only.  --gpus 1 takes the same path with a communicator of one.
 // --relaxed reads the OBJ with the tolerant parser and takes materials from its .mtl files;
 // --frames N re-renders from draw(dt) with the camera swinging sideways, N - 1 more times;
 // --smooth (with --relaxed) shades with the file's `vn` normals, interpolated (off: the reference's flat normals);
@@ -21,6 +25,7 @@
 #include <vector>
 
 #include "glwt.h"
+#include "multigpu.h"
 #include "objloader.h"
 #include "rt_shim.h"
 #include "texturerenderer.h"
@@ -36,12 +41,16 @@ struct Config {
     float mesh_reflect = 0.0f;                               // main.cpp:34: meshes do not reflect
     float wobble = 0.0f;
     int device = 0;
+    int gpus = 0, band_rows = 16;                            // --gpus N: N > 0 renders through multigpu.cpp
 } cfg;
 
 color *image = nullptr;                                      // main.cpp:16
 std::vector<float> image_rgb32, image_t, image_normal, image_uv;
 std::vector<int32_t> image_ids;
-rt_ctx *ctx = nullptr;
+rt_ctx *ctx = nullptr;                                       // the context (device cfg.device); with --gpus N the first of N
+std::vector<rt_ctx *> contexts;                              // every context: one per GPU
+MultiGpuFrame *multi = nullptr;
+bool image_pinned = false;                                   // `image` came from rt_alloc_host_buffer
 int exit_code = 0;
 int frames_rendered = 0;
 double total_rays = 0.0, total_device_ms = 0.0, total_refit_ms = 0.0, clock_s = 0.0;
@@ -80,20 +89,24 @@ bool check(int rc, const char *what)
     return false;
 }
 
-// Counterpart of LoadModel(const char*), main.cpp:219-232: parse, then hand the index
-// triples to the GPU, which runs the Triangle constructor for each.
-bool LoadModel(const char *model)
+// Counterpart of LoadModel(const char*), main.cpp:219-232: parse (once per process), then hand the index
+// triples to the GPU of context c, which runs the Triangle constructor for each.
+bool LoadModel(rt_ctx *c, const char *model)
 {
     static_assert(sizeof(vec3) == 3 * sizeof(float), "vec3 must be packed");
+    rt_ctx *const ctx = c;       // every call below goes to this context
     if (cfg.relaxed) {
-        ObjModel m;
-        if (!LoadModelEx(model, m)) {
+        static ObjModel m;
+        static bool parsed = false;
+        if (!parsed && !LoadModelEx(model, m)) {
             fprintf(stderr, "%s: cannot read\n", model);
             exit_code = 1;
             return false;
         }
-        if (m.dropped_faces || m.missing_materials)
+        if (!parsed && (m.dropped_faces || m.missing_materials))
             fprintf(stderr, "%s: %d face(s) dropped, %d unknown material name(s)\n", model, m.dropped_faces, m.missing_materials);
+        const bool first = !parsed;
+        parsed = true;
         std::vector<rt_material> mats;
         for (const ObjMaterial &om : m.materials)
             mats.push_back(material(om.reflect, om.diffuse, om.spec, om.color[0], om.color[1], om.color[2]));
@@ -117,17 +130,19 @@ bool LoadModel(const char *model)
         if (cfg.smooth) {
             std::vector<float> vn;
             const int with = CornerNormals(m, vn);
-            printf("%d of %zu triangles carry vn normals\n", with, m.tri_material.size());
+            if (first) printf("%d of %zu triangles carry vn normals\n", with, m.tri_material.size());
             if (with > 0 && !check(rt_set_triangle_normals(ctx, vn.data(), (int)m.tri_material.size()), "rt_set_triangle_normals"))
                 return false;
         }
         return true;
     }
-    std::vector<vec3> verts;
-    std::vector<vec2> uvs;
-    std::vector<vec3> normals;
-    std::vector<int> inds;
-    int malformed = LoadModel(model, verts, uvs, normals, inds);
+    static std::vector<vec3> verts;
+    static std::vector<vec2> uvs;
+    static std::vector<vec3> normals;
+    static std::vector<int> inds;
+    static bool parsed = false;
+    const int malformed = parsed ? 0 : LoadModel(model, verts, uvs, normals, inds);
+    parsed = true;
     if (malformed) {
         fprintf(stderr, "%s: %d malformed face line(s)\n", model, malformed);
         exit_code = 1;
@@ -142,6 +157,22 @@ bool LoadModel(const char *model)
 // One pass of the pixel loop (main.cpp:262-277) on the GPU into `image`.
 bool render_once(bool report)
 {
+    if (multi) {
+        uint64_t rays3[3];
+        float ms = 0.f;
+        if (!multigpu_render(multi, cfg.maxDepth, (uint8_t *)image, rays3, &ms)) {
+            exit_code = 1;
+            return false;
+        }
+        const double rays = (double)(rays3[0] + rays3[1] + rays3[2]);
+        frames_rendered++;
+        total_rays += rays;
+        total_device_ms += ms;
+        if (report)
+            printf("Render took %f seconds (longest device of %d), %.0f rays, %.1f Mrays/s\n", ms * 1e-3, (int)contexts.size(), rays,
+                   ms > 0 ? rays / (ms * 1e3) : 0.0);
+        return true;
+    }
     if (!image_t.empty()) {                        // EXR wanted: colour plus the t and normal planes
         rt_frame_planes planes = { (uint8_t *)image, image_ids.data(), image_rgb32.data(), image_t.data(), image_normal.data(),
                                    image_uv.empty() ? nullptr : image_uv.data() };
@@ -173,34 +204,58 @@ void setup()
 {
     texturerenderer_setup();
 
-    ctx = rt_create(cfg.device);
-    if (!ctx) {
-        fprintf(stderr, "rt_create failed: %s\n", rt_last_error());
+    if (rt_abi_version() != RT_ABI_VERSION) {
+        fprintf(stderr, "librt_amd.so speaks ABI version %d, this program %d\n", rt_abi_version(), RT_ABI_VERSION);
         exit_code = 1;
         return;
     }
-
-    if (cfg.builder && !check(rt_set_option(ctx, RT_OPT_BUILDER, cfg.builder), "rt_set_option(builder)")) return;
-    if (cfg.leaf_max && !check(rt_set_option(ctx, RT_OPT_LEAF_MAX, cfg.leaf_max), "rt_set_option(leaf max)")) return;
-
     // the stock scene, main.cpp:240-255
     std::vector<rt_analytic> scene;
     if (cfg.mirror) scene.push_back(sphere(0.0f, 0.0f, 0.0f, 2.5f, material(1.0f, 0.0f, 1.0f, 1.0f, 1.0f, 1.0f), false));
     scene.push_back(sphere(2.0f, 5.0f, 1.0f, 0.1f, material(0.0f, 1.0f, 1.0f, 0.7f, 0.7f, 0.9f), true));
     scene.push_back(sphere(-2.0f, 5.0f, -3.0f, 0.1f, material(0.0f, 1.0f, 1.0f, 0.9f, 0.9f, 0.4f), true));
     if (cfg.floor) scene.push_back(plane(0.0f, 1.0f, 0.0f, -4.0f, material(0.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f)));
-    if (!check(rt_set_analytic(ctx, scene.data(), (int)scene.size()), "rt_set_analytic")) return;
-
-    if (!cfg.obj.empty() && !LoadModel(cfg.obj.c_str())) return;               // main.cpp:257
-
     // camera of main.cpp:267-270; for another width the 8-unit horizontal span is kept
     rt_camera cam = { { 0.0f, 0.0f, -5.0f }, 0.01f, -4.0f, -4.0f, 0.0f };
     if (cfg.imageWidth != 800) cam.pitch = 8.0f / (float)cfg.imageWidth;
-    if (!check(rt_set_camera(ctx, &cam), "rt_set_camera")) return;
     base_cam = cam;
 
+    // one context per GPU, each with the whole scene (the hierarchy is built on every GPU: deterministic, so identical)
+    std::vector<int> devices;
+    for (int k = 0; k < (cfg.gpus > 0 ? cfg.gpus : 1); k++) {
+        rt_ctx *c = rt_create(cfg.device + k);
+        if (!c) {
+            fprintf(stderr, "rt_create(%d) failed: %s\n", cfg.device + k, rt_last_error());
+            exit_code = 1;
+            return;
+        }
+        contexts.push_back(c);
+        devices.push_back(cfg.device + k);
+        if (k == 0) ctx = c;
+        if (cfg.builder && !check(rt_set_option(c, RT_OPT_BUILDER, cfg.builder), "rt_set_option(builder)")) return;
+        if (cfg.leaf_max && !check(rt_set_option(c, RT_OPT_LEAF_MAX, cfg.leaf_max), "rt_set_option(leaf max)")) return;
+        if (!check(rt_set_analytic(c, scene.data(), (int)scene.size()), "rt_set_analytic")) return;
+        if (!cfg.obj.empty() && !LoadModel(c, cfg.obj.c_str())) return;        // main.cpp:257
+        if (!check(rt_set_camera(c, &cam), "rt_set_camera")) return;
+    }
+
     const size_t n = (size_t)cfg.imageWidth * cfg.imageHeight;
-    image = new color[n];                                                       // main.cpp:259
+    // main.cpp:259 allocates the image with new; here it comes pinned from the library, so the device writes it directly
+    image = (color *)rt_alloc_host_buffer(ctx, sizeof(color) * n);
+    image_pinned = image != nullptr;
+    if (!image) image = new color[n];
+    if (cfg.gpus > 0) {
+        if (!cfg.pfm.empty() || !cfg.ids.empty() || !cfg.exr.empty()) {
+            fprintf(stderr, "--gpus renders the 8-bit frame only (no --pfm, --ids, --exr)\n");
+            exit_code = 2;
+            return;
+        }
+        multi = multigpu_create(contexts, devices, cfg.imageWidth, cfg.imageHeight, cfg.band_rows);
+        if (!multi) {
+            exit_code = 1;
+            return;
+        }
+    }
     if (!cfg.pfm.empty() || !cfg.exr.empty()) image_rgb32.resize(3 * n);
     if (!cfg.ids.empty() || !cfg.exr.empty()) image_ids.resize(n);
     if (!cfg.exr.empty()) { image_t.resize(n); image_normal.resize(3 * n); if (have_uv) image_uv.resize(2 * n); }
@@ -233,7 +288,8 @@ void draw(float dt)
         const float swing = 1.5f * sinf((float)clock_s * 2.0f);
         cam.origin[0] += swing;
         cam.off_x += swing;
-        bool ok = check(rt_set_camera(ctx, &cam), "rt_set_camera");
+        bool ok = true;
+        for (rt_ctx *c : contexts) ok = ok && check(rt_set_camera(c, &cam), "rt_set_camera");
         if (ok && cfg.wobble != 0.0f && !rest_verts.empty()) {
             // a travelling wave through the mesh: same triangles, new positions, tree refitted on the device
             moved_verts.resize(rest_verts.size());
@@ -244,7 +300,8 @@ void draw(float dt)
                 moved_verts[k + 1] = y + cfg.wobble * 0.5f * sinf(ph * 1.3f + z * 0.5f);
                 moved_verts[k + 2] = z + cfg.wobble * cosf(ph + x * 0.6f);
             }
-            ok = check(rt_update_mesh_vertices(ctx, moved_verts.data(), (int)(moved_verts.size() / 3)), "rt_update_mesh_vertices");
+            for (rt_ctx *c : contexts)
+                ok = ok && check(rt_update_mesh_vertices(c, moved_verts.data(), (int)(moved_verts.size() / 3)), "rt_update_mesh_vertices");
             rt_stats st;
             if (ok && rt_get_stats(ctx, &st) == RT_OK) total_refit_ms += st.ms_build;
         }
@@ -317,11 +374,16 @@ int main(int argc, char *argv[])
         else if (a == "--wobble") cfg.wobble = (float)atof(val());
         else if (a == "--builder") cfg.builder = atoi(val());
         else if (a == "--leaf-max") cfg.leaf_max = atoi(val());
+        else if (a == "--gpus") cfg.gpus = atoi(val());
+        else if (a == "--band-rows") cfg.band_rows = atoi(val());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     glwt_headless_frames = cfg.frames > 1 ? cfg.frames : 1;
+    if (cfg.gpus < 0 || cfg.gpus > 64 || cfg.band_rows < 1) { fprintf(stderr, "--gpus takes 1..64, --band-rows a positive count\n"); return 2; }
     int rc = initglwt("Raytracer", cfg.imageWidth, cfg.imageHeight, false);    // main.cpp:291
-    if (ctx) rt_destroy(ctx);
-    delete[] image;
+    multigpu_destroy(multi);
+    if (image_pinned) (void)rt_free_host_buffer(ctx, image);
+    else delete[] image;
+    for (rt_ctx *c : contexts) rt_destroy(c);
     return rc ? rc : exit_code;
 }

@@ -121,3 +121,43 @@ def test_guarded_build_reports_a_traversal_stack_that_dropped_a_child():
     assert "NO ERROR" in run(0)
     out = run(1)
     assert "ERROR" in out and "guarded build" in out and "NO ERROR" not in out
+
+
+HOST_BIN = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+
+
+def _ppm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    w, h = map(int, parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_BIN), reason="host binary not built")
+def test_host_on_n_gpus_with_rccl_writes_the_single_context_frame(tmp_path):
+    """`raytracer --gpus N`: one process, one context per GPU, bands round-robin, ncclAllGather of the slices, bands put
+    back on GPU 0.  This box has one GPU, so N = 1 (a communicator of one, every step of the path still runs); the file
+    must equal the single-context frame byte for byte, also with bands that do not divide the height and over the
+    frames of the draw(dt) loop.  N > 1 is not measured on hardware here."""
+    from raytracer_amd import scenes
+    v, q = scenes.cube_quads()
+    obj = str(tmp_path / "cube.obj")
+    scenes.write_obj(obj, v, q)
+    base = [HOST_BIN, "--obj", obj, "--no-mirror", "--mesh-reflect", "0.5", "--width", "400", "--height", "301", "--depth", "3", "--raw-order"]
+    one, multi, odd = (str(tmp_path / n) for n in ("one.ppm", "multi.ppm", "odd.ppm"))
+    subprocess.run(base + ["--out", one], check=True, capture_output=True, timeout=120)
+    out = subprocess.run(base + ["--out", multi, "--gpus", "1"], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert "longest device of 1" in out
+    subprocess.run(base + ["--out", odd, "--gpus", "1", "--band-rows", "7"], check=True, capture_output=True, timeout=120)
+    ref = _ppm(one)
+    assert ref.shape == (301, 400, 3) and ref.max() > 0
+    assert np.array_equal(_ppm(multi), ref) and np.array_equal(_ppm(odd), ref)
+    # the draw(dt) loop: the last of three frames with the camera moving, on both paths
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    subprocess.run(base + ["--out", a, "--frames", "3"], check=True, capture_output=True, timeout=120)
+    subprocess.run(base + ["--out", b, "--frames", "3", "--gpus", "1"], check=True, capture_output=True, timeout=120)
+    assert np.array_equal(_ppm(a), _ppm(b)) and not np.array_equal(_ppm(a), ref)
+    # more GPUs than the box has is an error, not a crash
+    import torch
+    r = subprocess.run(base + ["--out", multi, "--gpus", str(torch.cuda.device_count() + 1)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rt_create" in r.stderr

@@ -331,16 +331,24 @@ def test_bench_reports_counter_traffic_only_for_the_sources_and_frame_it_was_mea
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     (tmp_path / "profiles").mkdir()
-    rec = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "bytes_per_frame": 123.0, "source": "x.txt"}}
+    rec = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "bytes_per_frame": 123.0, "bytes_per_frame_as_counted": 77.0, "source": "x.txt"}}
     (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
+    valu = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "source": "x", "kernels": {"k_trace<2, false, false>": {"active_lanes": 40.0}}}}
+    (tmp_path / "profiles" / "valu_counters.json").write_text(json.dumps(valu))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.measured_traffic("sponza", 1, (1920, 1080))[0] == 123.0
-    assert bench.measured_traffic("sponza", 1, (3840, 2160))[0] is None        # another frame size
-    assert bench.measured_traffic("soup", 1, (1920, 1080))[0] is None          # another workload
-    assert bench.measured_traffic("sponza", 2, (1920, 1080))[0] is None        # a partitioned run
+    assert bench.measured_traffic("sponza", 1, (1920, 1080))[0] == (123.0, 77.0)     # FETCH_SIZE doubled, and as counted
+    assert bench.measured_traffic("sponza", 1, (3840, 2160))[0] == (None, None)      # another frame size
+    assert bench.measured_traffic("soup", 1, (1920, 1080))[0] == (None, None)        # another workload
+    assert bench.measured_traffic("sponza", 2, (1920, 1080))[0] == (None, None)      # a partitioned run
+    assert bench.measured_valu("sponza", 1, (1920, 1080))[0]["k_trace<2, false, false>"]["active_lanes"] == 40.0
+    assert bench.measured_valu("sponza", 1, (1280, 720))[0] is None
     rec["source_hash"] = "0" * 16
     (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
+    valu["source_hash"] = "0" * 16
+    (tmp_path / "profiles" / "valu_counters.json").write_text(json.dumps(valu))
     got, why = bench.measured_traffic("sponza", 1, (1920, 1080))
+    assert got == (None, None) and "stale" in why
+    got, why = bench.measured_valu("sponza", 1, (1920, 1080))
     assert got is None and "stale" in why
     # the committed file itself is either valid for the committed sources or reported as stale, never silently wrong
     committed = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
