@@ -47,11 +47,11 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--leaf-max", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames a rank keeps in flight (one frame slot and stream each); 0 = 4 for frames of at most 10 M pixels, else 1: "
-                         "decided by the FRAME, never by the rank count, so every --gpus N of one workload runs in the same mode")
+                    help="frames a rank keeps in flight in the timed loop (one frame slot and stream each); 0 = 1, at every rank count")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (slices staged through host memory) is for rehearsing the partitioned job where RCCL cannot run")
     ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (rehearsal of N ranks on a one-GPU box; RCCL refuses that, use --backend gloo)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra loop with four frames in flight")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch of every frame instead of replaying a hipGraph")
     ap.add_argument("--builder", type=int, default=0, help="0 auto (= 3), 1 Karras LBVH, 2 PLOC, 3 binned SAH")
     ap.add_argument("--lib", default="", help="another build of librt_amd.so to load (A/B runs of kernel variants)")
@@ -238,16 +238,15 @@ def main():
         wl.load(c)
         return c
 
-    # One rank's share of a partitioned frame leaves most of the GPU idle (fewer rays than lanes, six dependent launches
-    # each as long as its longest rays), so a partitioned job keeps several frames in flight: one frame slot of the
-    # context, one stream and one buffer set each.  On one GPU the whole frame fills the chip and one slot is enough.
-    # (Measured on one GPU, share of 1080p: whole frame +1.6 %, half 1.14x, quarter 1.43x, eighth 1.9x with four slots: a share
-    # of more than ~1.5 M pixels fills the chip by itself and is not worth three more scene copies.)
-    # The mode is decided by the frame, not by the rank count: a 1 -> 8 curve of one workload compares like with like
-    # (one whole 1080p frame gains 3.5 % from four slots, an eighth of it 1.9x).  `frame_latency_ms` and `single_frame_value`
-    # give the same job one frame at a time, at every rank count.
-    in_flight = a.frames_in_flight if a.frames_in_flight > 0 else (4 if wl.W * wl.H <= 10_000_000 else 1)
+    # ONE mode for every rank count: a frame at a time, as the reference's setup() renders (main.cpp:262-277), so a 1 -> N curve
+    # compares like with like.  On one GPU that is also the fastest way to run whole frames (the traversal launches hand out
+    # their longest rays first, RT_OPT_CLAIM_ORDER, and leave little for a second frame to fill: four frames in flight are
+    # 2 % slower).  A rank's share of a partitioned frame is different: an eighth of 1080p has fewer rays than the GPU has
+    # lanes, and four frames in flight (one frame slot, stream and buffer set each) run 1.8x faster.  That rate is reported
+    # beside the headline as `pipelined`, at every rank count, never as `value`.
+    in_flight = a.frames_in_flight if a.frames_in_flight > 0 else 1
     ctx = make_context()
+    t_first = time.perf_counter()
     pr = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather, frames_in_flight=in_flight)
 
     def sync_all():
@@ -256,32 +255,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the very first frame of this layout: it includes the counting pass that makes the claim order, and the first
+    # launches' code loading
+    with torch.cuda.stream(pr.stream):
+        pr.render(slot=0)
+        sync_all()
+    first_frame_ms = (time.perf_counter() - t_first) * 1e3
+
     # the timed loop runs without per-launch device events, so that an unchanged frame replays as one
     # hipGraph; kernel times come from one more frame with the events on, outside the timed region
     ctx.set_option(rt.OPT_TIMING, 0)
-    frame_latency_ms = None
-    if in_flight == 1:
-        # (frame_latency_ms is then ms_per_step itself; filled in below)
+
+    def one_at_a_time(renderer, steps, warmup):
         # The loop runs on the renderer's own stream (made current here), so a frame costs no cross-stream events.
-        with torch.cuda.stream(pr.stream):
-            for _ in range(a.warmup):
-                pr.render()
+        with torch.cuda.stream(renderer.stream):
+            for _ in range(warmup):
+                renderer.render()
             sync_all()
             t0 = time.perf_counter()
-            for _ in range(a.steps):
-                pr.render()
+            for _ in range(steps):
+                renderer.render()
             sync_all()
-            dt = time.perf_counter() - t0
-        frame_latency_ms = dt / a.steps * 1e3
-    else:
-        # Frames go to the slots round-robin; the consumer of a frame (here: nothing but the wait) runs in_flight - 1
+            return time.perf_counter() - t0
+
+    def frames_in_flight(renderer, n, steps, warmup):
+        # Frames go to the slots round-robin; the consumer of a frame (here: nothing but the wait) runs n - 1
         # frames behind the producer, as a display or an encoder would.
         from collections import deque
         pending = deque()
 
         def step():
-            pending.append(pr.render_async())
-            if len(pending) >= in_flight:
+            pending.append(renderer.render_async())
+            if len(pending) >= n:
                 pending.popleft().wait()
 
         def drain():
@@ -289,18 +294,28 @@ def main():
                 pending.popleft().wait()
 
         with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-            for _ in range(max(a.warmup, 3) * in_flight):      # every slot replays a captured graph from its third frame on
+            for _ in range(max(warmup, 3) * n):      # every slot replays a captured graph from its third frame on
                 step()
             drain()
             sync_all()
             t0 = time.perf_counter()
-            for _ in range(a.steps):
+            for _ in range(steps):
                 step()
             drain()
             sync_all()
-            dt = time.perf_counter() - t0
-            # the same frames one at a time: what one frame takes from request to result
-            frame_latency_ms = timed_frames(pr.render, sync_all, min(a.steps, 20), 2)
+            return time.perf_counter() - t0
+
+    if in_flight == 1:
+        dt = one_at_a_time(pr, a.steps, a.warmup)
+        frame_latency_ms = dt / a.steps * 1e3
+    else:
+        dt = frames_in_flight(pr, in_flight, a.steps, a.warmup)
+        # the same frames one at a time: what one frame takes from request to result
+        frame_latency_ms = one_at_a_time(pr, min(a.steps, 20), 2) / min(a.steps, 20) * 1e3
+    pipelined = None
+    if in_flight == 1 and not a.no_pipelined and wl.W * wl.H <= 10_000_000:
+        pr4 = PartitionedRenderer(ctx, wl.W, wl.H, wl.max_depth, rank, world, a.band_rows, dev, dist=gather, frames_in_flight=4)
+        pipelined = frames_in_flight(pr4, 4, a.steps, a.warmup)
     with torch.cuda.stream(pr.stream):
         ctx.set_option(rt.OPT_TIMING, 1)
         pr.render(slot=0)
@@ -309,13 +324,16 @@ def main():
 
     rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
     vec = torch.tensor([dt, float(rays_local), float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"]),
-                        st["ms_trace"], st["ms_frame"]], dtype=torch.float64, device=dev)
+                        st["ms_trace"], st["ms_frame"], frame_latency_ms, pipelined if pipelined is not None else 0.0, first_frame_ms],
+                       dtype=torch.float64, device=dev)
     if dist is not None and a.backend != "nccl":
         vec = vec.cpu()
     mx, sm = reduce_over_ranks(vec, dist)        # times: max over ranks; ray counts: sum over ranks
     dt = float(mx[0])
     rays = float(sm[1]); rp, rs, rr = float(sm[2]), float(sm[3]), float(sm[4])
     ms_trace, ms_frame = float(mx[5]), float(mx[6])
+    frame_latency_ms, first_frame_ms = float(mx[7]), float(mx[9])
+    pipelined = float(mx[8]) if pipelined is not None else None
 
     # ---- roofline of the dominant kernel (k_bounce, all levels of one frame), rank 0's share:
     # algorithmic flops from a counting pass outside the timed region, duration from the
@@ -376,6 +394,12 @@ def main():
         # value are the rate with config.frames_in_flight frames in flight
         out["frame_latency_ms"] = frame_latency_ms
         out["single_frame_value"] = rays / frame_latency_ms / 1e3
+        # the first frame a new context renders: scene resident, but with the counting pass that makes the claim order
+        # (RT_OPT_CLAIM_ORDER) and the first launches' code loading; every later frame of the layout is a `step`
+        out["first_frame_ms"] = first_frame_ms
+        if pipelined is not None:
+            out["pipelined"] = {"frames_in_flight": 4, "ms_per_step": pipelined / a.steps * 1e3, "value": rays * a.steps / pipelined / 1e6,
+                                "unit": "Mrays/s", "note": "the same job with four frames in flight per rank; not the headline"}
         if world == 1 and not a.no_extras:
             # the same frames with every launch issued one by one (a frame that changes cannot replay a graph)
             ctx.set_option(rt.OPT_TIMING, 0)

@@ -13,7 +13,7 @@ OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --frames-in-flight 1 $*"
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-pipelined --frames-in-flight 1 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; exit 1; }
 i=0
 for PMC in \

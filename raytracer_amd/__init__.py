@@ -20,6 +20,7 @@ PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 OPT_BUILDER = 6
 OPT_GRAPH = 7
 OPT_SPLIT = 8
+OPT_CLAIM_ORDER = 9
 BUILDER_AUTO, BUILDER_LBVH, BUILDER_PLOC, BUILDER_SAH = 0, 1, 2, 3
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 RT_MAX_ANALYTIC, RT_MAX_DEPTH, RT_BRUTE_MAX = 1024, 64, 48

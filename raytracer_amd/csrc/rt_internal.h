@@ -155,6 +155,8 @@ struct FrameParams {
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
     int wide_depth;                // depth of the 4-wide tree
     int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages
+    int track_units;               // staged pipeline: record every claim unit's longest ray (with count_tests; FrameWorkspace::unit_cost)
+    int use_order;                 // staged pipeline: claim the units in the order of FrameWorkspace::unit_order
     float *d_normal;               // optional device plane: the primary hit's normal, 3 floats per pixel (0 on a miss)
     float *d_uv;                   // optional device plane: the primary hit's texture coordinate, 2 floats per pixel
 };
@@ -177,6 +179,16 @@ struct FrameWorkspace {
     int *overflow = nullptr;       // traversal stack spill columns
     size_t slots_cap = 0, overflow_cap = 0;
     int chunks_cap = 0, seg_cap = 0;
+    // Claim order of the traversal launches.  A launch ends with its longest rays; when those are claimed last, the chip
+    // idles behind them.  unit_cost[launch][unit] = steps of the longest ray of each 64-ray claim unit, recorded by a
+    // counting frame; unit_order[launch][k] = the unit claimed k-th: longest first.  A frame with the same layout (frame
+    // size, rows, depth, lights) claims in that order, whatever moved in between: the order only decides when a ray
+    // is traced, never what it hits.
+    unsigned int *unit_cost = nullptr, *unit_order = nullptr;
+    size_t unit_stride = 0;        // entries per launch
+    int unit_launches = 0;         // launches the arrays have room for
+    bool order_valid = false;
+    std::vector<unsigned char> order_key;   // the frame layout unit_order was made for
     // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
     unsigned int *p_occ = nullptr; // [levels][chunks][pixels] occlusion bit per light, 32 lights per chunk
@@ -203,6 +215,8 @@ int wavefront_trace_grid(int num_cus);
 size_t wavefront_overflow_ints(int num_cus);
 size_t wavefront_regions(size_t slots);
 size_t wavefront_cursor_words(int levels, int n_chunks);
+size_t wavefront_unit_stride(size_t slots, int n_lights);   // claim units of the largest traversal launch of a frame
+int wavefront_unit_launches(int levels, int n_chunks);      // traversal launches a frame may have
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
                     const std::function<int()> &stamp, int *n_launches, std::string *err);

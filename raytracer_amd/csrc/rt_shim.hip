@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -99,6 +100,8 @@ struct rt_ctx {
     int opt_accel = 0, opt_count = 0, opt_leaf_max = 2, opt_timing = 1, opt_pipeline = 0, opt_builder = 0, opt_split = 0;
     DevCamera cam;
     int opt_graph = 1;                       // replay of an unchanged frame's launches (only with timing and test counting off)
+    int opt_claim_order = getenv("RT_CLAIM_ORDER") ? atoi(getenv("RT_CLAIM_ORDER")) : 1;   // RT_OPT_CLAIM_ORDER (the variable sets the default, for A/B runs)
+    unsigned long long scene_version = 0;    // bumped when primitives are replaced (not when they move)
     unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
     unsigned char *scratch_ptr = nullptr;    // this device's copy of the no-alloc scratch array (set by rt_create)
     // Host hand-over of rt_render_frame / rt_render_frame_planes: a pinned staging buffer the device copies into at
@@ -176,6 +179,7 @@ void drop_graphs(rt_ctx *c)
 void free_triangles(rt_ctx *c)
 {
     c->state_version++;
+    c->scene_version++;
     if (c->d_tri_mt) (void)hipFree(c->d_tri_mt);
     if (c->d_tri_n) (void)hipFree(c->d_tri_n);
     if (c->d_mats) (void)hipFree(c->d_mats);
@@ -197,7 +201,7 @@ void free_workspace(FrameWorkspace &ws)
 {
     void *ptrs[] = { ws.records, ws.hit_t, ws.queue_o[0], ws.queue_o[1], ws.queue_d[0], ws.queue_d[1], ws.counters,
                      ws.out_rgb8, ws.out_id, ws.out_rgb32, ws.out_normal, ws.out_uv, ws.sq_o, ws.rq_counts[0], ws.rq_counts[1],
-                     ws.sq_counts, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1] };
+                     ws.sq_counts, ws.overflow, ws.p_hits, ws.p_occ, ws.fq_counts[0], ws.fq_counts[1], ws.unit_cost, ws.unit_order };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -274,6 +278,19 @@ int ensure_workspace(rt_ctx *c, size_t pixels, size_t slots, int levels, int pip
             if (e == hipSuccess) e = hipMalloc((void **)&ws.sq_counts, sizeof(unsigned int) * regions * (size_t)(gc ? gc : 1));
             if (e != hipSuccess) return fail(RT_E_NOMEM, std::string("wavefront workspace: ") + hipGetErrorString(e));
             ws.slots_cap = sc; ws.chunks_cap = cc; ws.seg_cap = gc;
+        }
+        // claim-order arrays: one row of units per traversal launch
+        const size_t stride = wavefront_unit_stride(slots > pixels ? slots : pixels, c->n_lights);
+        const int n_launch = wavefront_unit_launches(levels, n_chunks);
+        if (stride * (size_t)n_launch > ws.unit_stride * (size_t)ws.unit_launches || stride != ws.unit_stride) {
+            if (ws.unit_cost) (void)hipFree(ws.unit_cost);
+            if (ws.unit_order) (void)hipFree(ws.unit_order);
+            ws.unit_cost = ws.unit_order = nullptr; ws.unit_stride = 0; ws.unit_launches = 0; ws.order_valid = false;
+            const size_t n = stride * (size_t)n_launch;
+            if (hipMalloc((void **)&ws.unit_cost, sizeof(unsigned int) * n) != hipSuccess ||
+                hipMalloc((void **)&ws.unit_order, sizeof(unsigned int) * n) != hipSuccess)
+                return fail(RT_E_NOMEM, "hipMalloc(claim order) failed");
+            ws.unit_stride = stride; ws.unit_launches = n_launch;
         }
         const size_t ovf = wavefront_overflow_ints(cus);
         if (ovf > ws.overflow_cap) {
@@ -431,6 +448,54 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     std::string err;
     int launches = 0;
     int rc = RT_OK;
+    if (c->opt_claim_order == 2) {          // asked for a new order: every slot makes one at its next frame
+        for (FrameSlot &f : c->slots) f.ws.order_valid = false;
+        c->opt_claim_order = 1;
+    }
+    if (wavefront && c->opt_claim_order && c->f->ws.unit_cost) {
+        // The claim order of this frame layout: made once, by a counting frame that records every unit's longest ray, and
+        // used by every later frame of the layout (a moved camera or refitted mesh keeps it: it only decides WHEN a ray
+        // is traced).  A new mesh or new analytic primitives (state_version) make a new one.
+        struct OrderKey { int W, depth, n_lights, n_analytic, n_tris; rt_rowset rows; unsigned long long scene; } ok;
+        memset(&ok, 0, sizeof ok);
+        ok.W = W; ok.depth = max_depth; ok.n_lights = c->n_lights; ok.n_analytic = c->n_analytic; ok.n_tris = c->n_tris; ok.rows = *rows;
+        ok.scene = c->scene_version;
+        FrameWorkspace &ws = c->f->ws;
+        if (!ws.order_valid || ws.order_key.size() != sizeof ok || memcmp(ws.order_key.data(), &ok, sizeof ok) != 0) {
+            ws.order_valid = false;
+            FrameParams cal = fp;
+            cal.count_tests = 1; cal.timing = 0; cal.track_units = 1; cal.use_order = 0;
+            const size_t n = ws.unit_stride * (size_t)ws.unit_launches;
+            if (hipMemsetAsync(ws.unit_cost, 0, sizeof(unsigned int) * n, stream) != hipSuccess) return fail(RT_E_DEVICE, "clear unit costs");
+            int cal_launches = 0;
+            rc = trace_frame(sc, c->cam, cal, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &cal_launches, &err);
+            if (rc != RT_OK) return fail(rc, err);
+            std::vector<unsigned int> cost(n), order(n);
+            if (hipMemcpyAsync(cost.data(), ws.unit_cost, sizeof(unsigned int) * n, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                return fail(RT_E_DEVICE, "read unit costs");
+            // per launch: units by falling cost, equal costs by rising index (a counting sort; costs are step counts).  Units
+            // past the launch's own count cost nothing and therefore come last: the first n_units entries of a row are a
+            // permutation of that launch's units.
+            constexpr unsigned int BUCKETS = 4096;
+            std::vector<size_t> start(BUCKETS + 1);
+            for (int l = 0; l < ws.unit_launches; l++) {
+                unsigned int *o = order.data() + (size_t)l * ws.unit_stride;
+                const unsigned int *cs = cost.data() + (size_t)l * ws.unit_stride;
+                std::fill(start.begin(), start.end(), (size_t)0);
+                auto bucket = [](unsigned int v) { return BUCKETS - 1 - (v < BUCKETS ? v : BUCKETS - 1); };     // high cost first
+                for (size_t k = 0; k < ws.unit_stride; k++) start[bucket(cs[k]) + 1]++;
+                for (unsigned int b = 0; b < BUCKETS; b++) start[b + 1] += start[b];
+                for (size_t k = 0; k < ws.unit_stride; k++) o[start[bucket(cs[k])]++] = (unsigned int)k;
+            }
+            if (hipMemcpyAsync(ws.unit_order, order.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                return fail(RT_E_DEVICE, "upload claim order");
+            ws.order_key.assign((const unsigned char *)&ok, (const unsigned char *)&ok + sizeof ok);
+            ws.order_valid = true;
+        }
+        fp.use_order = 1;
+    }
     const bool want_graph = c->opt_graph && !fp.timing && !fp.count_tests;
     if (want_graph) {
         // The launches of a frame depend only on these values: when none changed since the last frame,
@@ -685,6 +750,10 @@ int rt_set_option(rt_ctx *c, int option, int value)
         c->opt_split = value;
         return RT_OK;
     case RT_OPT_GRAPH: c->opt_graph = value ? 1 : 0; drop_graphs(c); return RT_OK;
+    case RT_OPT_CLAIM_ORDER:
+        if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_CLAIM_ORDER takes 0, 1 or 2");
+        c->opt_claim_order = value;
+        return RT_OK;
     case RT_OPT_PIPELINE:
         if (value < 0 || value > 2) return fail(RT_E_INVALID, "RT_OPT_PIPELINE takes 0, 1 or 2");
         c->opt_pipeline = value;
@@ -717,6 +786,7 @@ int rt_set_analytic(rt_ctx *c, const rt_analytic *prims, int n)
     }
     DeviceGuard g(c->device);
     quiesce(c);
+    c->scene_version++;
     if (c->d_analytic) (void)hipFree(c->d_analytic);
     if (c->d_lights) (void)hipFree(c->d_lights);
     c->d_analytic = nullptr; c->d_lights = nullptr; c->n_analytic = 0; c->n_lights = 0;

@@ -109,6 +109,8 @@ struct TraceArgs {
     unsigned int n_pix;                 // entries of the hit and occlusion planes
     unsigned int n_wnodes;              // entries of sc.wnodes
     unsigned long long *wave_times; // diagnostic (RT_WF_TIMES): [wave][3] 100 MHz clock at start, when nothing was left to claim, at exit
+    const unsigned int *order;      // [n_units] the unit the k-th claim takes (longest rays first), or null: unit k
+    unsigned int *cost;             // [n_units] COUNT builds: steps of the longest ray of every unit (atomic max), or null
 };
 
 // MODE 0: nearest hit of every ray of one queue (or of the camera rays, PRIMARY).
@@ -138,6 +140,7 @@ void k_trace(TraceArgs A)
     Tally tl = { 0u, 0u, 0u };
     unsigned int dbg[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes, idle / leaf-waiting lanes at node steps
     unsigned int box_slots = 0, nsteps = 0;                     // COUNT: box tests on occupied child slots; node steps of this lane's ray
+    unsigned int cur_unit = 0, my_unit = 0, ray_steps = 0;      // COUNT: the unit being dealt out; this lane's ray's unit and steps so far
     __shared__ unsigned long long s_coh[COUNT ? 3 * 16 * 4 : 1];
     if (COUNT) {
         for (int k = threadIdx.x; k < 3 * 16 * 4; k += BLOCK) s_coh[k] = 0ull;
@@ -192,6 +195,11 @@ void k_trace(TraceArgs A)
             break;
         }
 #endif
+        if (COUNT && A.cost && node == NODE_SENTINEL && ray_steps != 0u) {
+            // a ray has ended since the last look: its unit remembers its longest ray
+            atomicMax(&A.cost[RTG(my_unit, n_units)], ray_steps);
+            ray_steps = 0u;
+        }
         // ---- refill idle lanes from the local range; claim a new unit when it is empty
         const unsigned long long idle = __ballot(node == NODE_SENTINEL);
         if (!exhausted && idle != 0ull && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
@@ -210,7 +218,9 @@ void k_trace(TraceArgs A)
                     }
                     continue;
                 }
-                const unsigned int u = (unsigned)unit;
+                unsigned int u = (unsigned)unit;
+                if (A.order) u = (unsigned)RTG(A.order[u], n_units);     // the claim order of the launch: units with long rays first
+                if (COUNT) cur_unit = u;
                 const unsigned int per_seg = (unsigned)A.n_regions * UPR;
                 seg = (int)(u / per_seg);
 #if WF_CLOSEST_FIRST
@@ -269,7 +279,7 @@ void k_trace(TraceArgs A)
 #if WF_SETASIDE
                     stash = 0;
 #endif
-                    if (COUNT) nsteps = 0;
+                    if (COUNT) { nsteps = 0; my_unit = cur_unit; ray_steps = 1u; }
                 }
             }
             cur = min(end, cur + (unsigned)__popcll(idle));
@@ -318,8 +328,9 @@ void k_trace(TraceArgs A)
                     if (oct == first_oct) atomicAdd(c + 3, 1ull);
                 }
             }
-            if (at) nsteps++;
+            if (at) { nsteps++; ray_steps++; }
         }
+        if (COUNT && do_leaf && node < 0) ray_steps++;
         if (do_node) {
             // ---- inner-node step: four children per 64-byte node
             if ((unsigned)node < SENT_U) {
@@ -526,12 +537,22 @@ void k_trace(TraceArgs A)
 constexpr int PK_STACK = 64;
 typedef float PkF16 __attribute__((ext_vector_type(16)));
 typedef float PkF4 __attribute__((ext_vector_type(4)));
+#ifndef PK_VECTOR_LOADS
+#define PK_VECTOR_LOADS 0
+#endif
+#if PK_VECTOR_LOADS
+// the same wave-uniform addresses through the vector memory path: every lane receives the same 16 bytes
+typedef const PkF4 *ConstF4P;
+#else
 // loads through the constant address space with a wave-uniform address: scalar loads (s_load_dwordx16 / x4)
-typedef const __attribute__((address_space(4))) PkF16 *ConstF16P;
 typedef const __attribute__((address_space(4))) PkF4 *ConstF4P;
+#endif
 
+#ifndef PK_WAVES
+#define PK_WAVES 8
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_packet(TraceArgs A)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES))) void k_trace_packet(TraceArgs A)
 {
     static_assert(UNIT <= 64, "a packet is one wave");
     const int lane = threadIdx.x & 63;
@@ -556,7 +577,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (++probes >= max_probes) break;
             continue;
         }
-        const unsigned int u = (unsigned)unit, region = u / UPR, sub = u % UPR, r0 = region * REGION;
+        unsigned int u = (unsigned)unit;
+        if (A.order) u = (unsigned)RTG(A.order[u], n_units);
+        const unsigned int region = u / UPR, sub = u % UPR, r0 = region * REGION;
+        unsigned int packet_steps = 0;
         const unsigned int cnt = A.n_slots > r0 ? min((unsigned)REGION, A.n_slots - r0) : 0u;
         const unsigned int cur = r0 + sub * UNIT, end = r0 + min(sub * UNIT + UNIT, cnt);
         if (cur >= end) continue;
@@ -576,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // When every ray of the tile points into the same octant, near and far planes are picked once per wave.
         const unsigned long long mx = __ballot(live && inv.x < 0.0f), my_ = __ballot(live && inv.y < 0.0f), mz = __ballot(live && inv.z < 0.0f);
         const bool uni = (mx == 0ull || mx == alive) && (my_ == 0ull || my_ == alive) && (mz == 0ull || mz == alive);
-        const bool sx = mx != 0ull, sy = my_ != 0ull, sz = mz != 0ull;
+        const int ix = mx != 0ull ? 1 : 0, iy = my_ != 0ull ? 1 : 0, iz = mz != 0ull ? 1 : 0;    // which plane of a pair comes first
 
         int stackv = 0;          // the packet's stack: lane k holds entry k
         int sp = 0, node = 0;    // wave-uniform
@@ -588,15 +612,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             }
 #endif
             if (node >= 0) {
-                // BvhNode4F through the scalar cache: lo_x hi_x lo_y hi_y lo_z hi_z ref (pad is not read)
+                // BvhNode4F: lo_x hi_x lo_y hi_y lo_z hi_z ref (pad is not read), 16 bytes each, at a wave-uniform address
                 ConstF4P np = (ConstF4P)(unsigned long long)(sc.fnodes + (unsigned)RTG(node, A.n_wnodes));
-                const PkF4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], rf = np[6];
+                const PkF4 rf = np[6];
                 unsigned int key[4];
                 const int ref[4] = { __float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w) };
                 float tn[4], tf[4];
                 if (uni) {
-                    // the planes every ray meets first / last, picked once for the wave
-                    const PkF4 ax = sx ? hx : lx, bx = sx ? lx : hx, ay = sy ? hy : ly, by = sy ? ly : hy, az = sz ? hz : lz, bz = sz ? lz : hz;
+                    // the planes every ray meets first / last: picked once for the wave, by address
+                    const PkF4 ax = np[ix], bx = np[1 - ix], ay = np[2 + iy], by = np[3 - iy], az = np[4 + iz], bz = np[5 - iz];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         tn[c] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ax[c], inv.x, oi.x), __builtin_fmaf(ay[c], inv.y, oi.y)),
@@ -605,6 +629,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                       __builtin_fmaf(bz[c], inv.z, oi.z)), best_t);
                     }
                 } else {
+                    const PkF4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const float x0 = __builtin_fmaf(lx[c], inv.x, oi.x), x1 = __builtin_fmaf(hx[c], inv.x, oi.x);
@@ -623,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     if (m != 0ull) key[c] = (unsigned)__builtin_amdgcn_readlane(__float_as_int(tn[c]), __ffsll((long long)m) - 1);
                     if (COUNT) box_slots += (live && ref[c] != NODE_SENTINEL) ? 1u : 0u;
                 }
-                if (COUNT) { tl.box += live ? 4u : 0u; n_node_steps++; n_node_lanes += (unsigned)__popcll(alive); }
+                if (COUNT) { tl.box += live ? 4u : 0u; n_node_steps++; n_node_lanes += (unsigned)__popcll(alive); packet_steps++; }
                 // children by the first entering lane's entry distance (non-negative floats order like their bits); all scalar
 #define PK_CSWAP(a, b)                                                          \
                 if (key[b] < key[a]) {                                          \
@@ -662,13 +687,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     }
                     if (COUNT && live) tl.tri += 1;
                 }
-                if (COUNT) { n_leaf_steps++; n_leaf_lanes += (unsigned)__popcll(alive); }
+                if (COUNT) { n_leaf_steps++; n_leaf_lanes += (unsigned)__popcll(alive); packet_steps++; }
                 if (sp == 0) break;
                 sp--;
                 node = __builtin_amdgcn_readlane(stackv, sp);
             }
         }
         if (live) A.hits[RTG((unsigned)pr.pixel, A.n_pix)] = make_float2(best_t, __int_as_float(best_id));
+        if (COUNT && A.cost && lane == 0) A.cost[RTG(u, n_units)] = packet_steps;
     }
     if (COUNT) {
         unsigned int vals[4] = { tl.box, tl.tri, tl.analytic, box_slots };
@@ -849,6 +875,11 @@ size_t wavefront_cursor_words(int levels, int n_chunks)
 {
     return (size_t)SHARDS * CURSOR_STRIDE * (size_t)levels * (size_t)(1 + n_chunks);
 }
+size_t wavefront_unit_stride(size_t slots, int n_lights)
+{
+    return (size_t)((n_lights < 32 ? n_lights : 32) + 1) * wavefront_regions(slots) * UPR;
+}
+int wavefront_unit_launches(int levels, int n_chunks) { return levels * (1 + n_chunks) + 1; }
 
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
@@ -940,8 +971,13 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         launches++;
     };
     // mode 0: nearest hit of `level`; 1: shadow rays of (level, chunk); 2: shadow rays of (level, chunk) + nearest hit of level + 1
+    int launch_index = 0;
     auto launch_traversal = [&](int mode, int level, int chunk) -> int {
         t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
+        const bool units_ok = ws.unit_cost && launch_index < ws.unit_launches;
+        t.cost = (fp.track_units && count && units_ok) ? ws.unit_cost + (size_t)launch_index * ws.unit_stride : nullptr;
+        t.order = (fp.use_order && units_ok) ? ws.unit_order + (size_t)launch_index * ws.unit_stride : nullptr;
+        launch_index++;
         const int close_level = mode == 2 ? level + 1 : level;
         t.hits = hits_of(close_level);
         if (mode == 0) {
@@ -969,7 +1005,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         if (int rc = tstamp()) return rc;
         if (primary && packet) {
             // one wave per 8x8 tile: 8 waves per SIMD fit (few vector registers, no LDS)
-            const int pgrid = num_cus * 8;
+            const int pgrid = num_cus * PK_WAVES;
             if (count) hipLaunchKernelGGL(k_trace_packet<true>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
             else hipLaunchKernelGGL(k_trace_packet<false>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
         } else if (primary) launch_trace<0, true>(t, count, grid, stream);

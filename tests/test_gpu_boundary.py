@@ -161,3 +161,52 @@ def test_host_on_n_gpus_with_rccl_writes_the_single_context_frame(tmp_path):
     import torch
     r = subprocess.run(base + ["--out", multi, "--gpus", str(torch.cuda.device_count() + 1)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "rt_create" in r.stderr
+
+
+def test_claim_order_changes_when_rays_are_traced_never_what_they_hit():
+    """RT_OPT_CLAIM_ORDER: the first frame of a layout is preceded by a counting pass, later frames hand their work units out
+    longest rays first.  Every plane and every ray count must be what they are with the option off: on the frame the order
+    was made for, on a frame with the camera moved (the order is then stale), after asking for a new order, and with test
+    counting on."""
+    import torch
+    W, H, D = 640, 400, 4
+
+    def frame(ctx):
+        rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        hid = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        rgb32 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        ht = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        ctx.render_rows_device(W, H, rt.RowSet(0, 1, 1, H), D, rgb8.data_ptr(), hid.data_ptr(), rgb32.data_ptr(), ht.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = ctx.stats()
+        return (rgb8.cpu().numpy(), hid.cpu().numpy(), rgb32.cpu().numpy().view(np.uint32), ht.cpu().numpy().view(np.uint32),
+                (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]))
+
+    def same(a, b):
+        return all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
+
+    cams = [rt.Camera(origin=(0.0, -1.5, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4),
+            rt.Camera(origin=(1.0, -1.0, -6.0), pitch=8.0 / W, off_x=-3.0, off_y=-3.0)]
+    with rt.Context(0) as off, rt.Context(0) as on:
+        for ctx, value in ((off, 0), (on, 1)):
+            ctx.set_option(rt.OPT_CLAIM_ORDER, value)
+            to_product(ctx, atrium_spec(detail=0.05))
+        with pytest.raises(rt.RtError):
+            on.set_option(rt.OPT_CLAIM_ORDER, 3)
+        ref = []
+        for cam in cams:
+            off.set_camera(cam)
+            ref.append(frame(off))
+        assert ref[0][4][1] > 0 and ref[0][4][2] > 0 and not same(ref[0], ref[1])
+        on.set_camera(cams[0])
+        assert same(frame(on), ref[0])          # the frame that made the order (counting pass + frame)
+        assert same(frame(on), ref[0])          # the same frame in the recorded order
+        assert same(frame(on), ref[0])          # ... replayed as a graph
+        on.set_camera(cams[1])
+        assert same(frame(on), ref[1])          # another view under the first view's order
+        on.set_option(rt.OPT_CLAIM_ORDER, 2)    # a new order for this view
+        assert same(frame(on), ref[1]) and same(frame(on), ref[1])
+        on.set_option(rt.OPT_COUNT_TESTS, 1)
+        assert same(frame(on), ref[1])
+        assert on.stats()["box_tests"] > 0
