@@ -157,6 +157,8 @@ struct FrameParams {
     int pipeline;                  // 0 auto, 1 fused bounce kernel, 2 wavefront stages
     int track_units;               // staged pipeline: record every claim unit's longest ray (with count_tests; FrameWorkspace::unit_cost)
     int use_order;                 // staged pipeline: claim the units in the order of FrameWorkspace::unit_order
+    int camera_packet;             // staged pipeline: 1 = the camera rays go through the packet kernel (one wave walks the tree for a tile)
+    int camera_only;               // staged pipeline: enqueue the camera rays' traversal launch and nothing else (timing runs)
     float *d_normal;               // optional device plane: the primary hit's normal, 3 floats per pixel (0 on a miss)
     float *d_uv;                   // optional device plane: the primary hit's texture coordinate, 2 floats per pixel
 };
@@ -188,6 +190,7 @@ struct FrameWorkspace {
     size_t unit_stride = 0;        // entries per launch
     int unit_launches = 0;         // launches the arrays have room for
     bool order_valid = false;
+    int camera_packet = 0;         // which camera-ray kernel was faster for this layout when the order was made
     std::vector<unsigned char> order_key;   // the frame layout unit_order was made for
     // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
@@ -217,6 +220,7 @@ size_t wavefront_regions(size_t slots);
 size_t wavefront_cursor_words(int levels, int n_chunks);
 size_t wavefront_unit_stride(size_t slots, int n_lights);   // claim units of the largest traversal launch of a frame
 int wavefront_unit_launches(int levels, int n_chunks);      // traversal launches a frame may have
+bool wavefront_packet_possible(const DevScene &scene, const FrameParams &fp);   // the packet kernel can walk this hierarchy
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
                     const std::function<int()> &stamp, int *n_launches, std::string *err);

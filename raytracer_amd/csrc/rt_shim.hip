@@ -102,6 +102,7 @@ struct rt_ctx {
     int opt_graph = 1;                       // replay of an unchanged frame's launches (only with timing and test counting off)
     int opt_claim_order = getenv("RT_CLAIM_ORDER") ? atoi(getenv("RT_CLAIM_ORDER")) : 1;   // RT_OPT_CLAIM_ORDER (the variable sets the default, for A/B runs)
     unsigned long long scene_version = 0;    // bumped when primitives are replaced (not when they move)
+    int opt_camera_packet = getenv("RT_WF_PACKET") ? atoi(getenv("RT_WF_PACKET")) : -1;   // -1: whichever was faster when the claim order was made; 0 / 1 force
     unsigned long long state_version = 0;   // bumped by anything that changes device pointers or the scene
     unsigned char *scratch_ptr = nullptr;    // this device's copy of the no-alloc scratch array (set by rt_create)
     // Host hand-over of rt_render_frame / rt_render_frame_planes: a pinned staging buffer the device copies into at
@@ -493,9 +494,40 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
                 return fail(RT_E_DEVICE, "upload claim order");
             ws.order_key.assign((const unsigned char *)&ok, (const unsigned char *)&ok + sizeof ok);
             ws.order_valid = true;
+            // Which kernel for the camera rays?  Packets (one wave walks the tree once for the 64 rays of a tile) win where
+            // tiles see large surfaces and lose where they see slivers and wires; both are timed here, once, on this very
+            // frame (second run of each: the first loads the code), and the faster one serves the layout.
+            ws.camera_packet = 0;
+            if (c->opt_camera_packet < 0 && wavefront_packet_possible(sc, fp)) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                    if (e0) (void)hipEventDestroy(e0);
+                    return fail(RT_E_DEVICE, "hipEventCreate failed");
+                }
+                float ms[2] = { 0.f, 0.f };
+                FrameParams cam_only = fp;
+                cam_only.count_tests = 0; cam_only.timing = 0; cam_only.use_order = 1; cam_only.camera_only = 1;
+                for (int mode = 0; mode < 2 && rc == RT_OK; mode++) {
+                    cam_only.camera_packet = mode;
+                    for (int run = 0; run < 2 && rc == RT_OK; run++) {
+                        int n_l = 0;
+                        if (run == 1 && hipEventRecord(e0, stream) != hipSuccess) rc = RT_E_DEVICE;
+                        if (rc == RT_OK) rc = trace_frame(sc, c->cam, cam_only, ws, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream, &n_l, &err);
+                        if (rc == RT_OK && run == 1 && (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                                                        hipEventElapsedTime(&ms[mode], e0, e1) != hipSuccess))
+                            rc = RT_E_DEVICE;
+                    }
+                }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                if (rc != RT_OK) return fail(rc, err.empty() ? "timing the camera-ray kernels failed" : err);
+                ws.camera_packet = ms[1] < ms[0] ? 1 : 0;
+                if (getenv("RT_WF_DEBUG")) fprintf(stderr, "[rt] camera rays: per-lane %.3f ms, packets %.3f ms -> %s\n", ms[0], ms[1], ws.camera_packet ? "packets" : "per-lane");
+            }
         }
         fp.use_order = 1;
     }
+    fp.camera_packet = c->opt_camera_packet >= 0 ? c->opt_camera_packet : ((wavefront && c->opt_claim_order) ? c->f->ws.camera_packet : 0);
     const bool want_graph = c->opt_graph && !fp.timing && !fp.count_tests;
     if (want_graph) {
         // The launches of a frame depend only on these values: when none changed since the last frame,

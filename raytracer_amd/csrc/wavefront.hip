@@ -531,9 +531,6 @@ void k_trace(TraceArgs A)
 // A leaf's triangles come through the scalar cache too and every lane runs the reference's own test on them
 // (main.cpp:109-129).  The hierarchy only prunes and ties go to the lowest id explicitly, so the hits are those of
 // k_trace bit for bit; the box arithmetic is the same fused multiply-add on the same values.
-#ifndef WF_PACKET
-#define WF_PACKET 1
-#endif
 constexpr int PK_STACK = 64;
 typedef float PkF16 __attribute__((ext_vector_type(16)));
 typedef float PkF4 __attribute__((ext_vector_type(4)));
@@ -880,6 +877,7 @@ size_t wavefront_unit_stride(size_t slots, int n_lights)
     return (size_t)((n_lights < 32 ? n_lights : 32) + 1) * wavefront_regions(slots) * UPR;
 }
 int wavefront_unit_launches(int levels, int n_chunks) { return levels * (1 + n_chunks) + 1; }
+bool wavefront_packet_possible(const DevScene &scene, const FrameParams &fp) { return scene.fnodes && 3 * fp.wide_depth + 1 <= PK_STACK; }
 
 int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FrameParams &fp, FrameWorkspace &ws, void *d_rgb8,
                     void *d_hit_id, void *d_rgb32, void *d_hit_t, hipStream_t stream, int num_cus,
@@ -955,9 +953,8 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     // run, and neither needs the other: they share one traversal launch (WF_MERGE), so a frame of D
     // bounces has D + 2 traversal drains instead of 2 D + 2.
     const bool merge = WF_MERGE != 0;
-    // camera rays as wave packets (RT_WF_PACKET=0/1 overrides the build's default); the packet's stack is one register
-    static const int packet_opt = [] { const char *e = getenv("RT_WF_PACKET"); return e ? atoi(e) : WF_PACKET; }();
-    const bool packet = packet_opt != 0 && scene.fnodes && 3 * fp.wide_depth + 1 <= PK_STACK;
+    // camera rays as wave packets when the caller found them faster for this layout; the packet's stack is one register
+    const bool packet = fp.camera_packet != 0 && wavefront_packet_possible(scene, fp);
     auto launch_gen = [&](int level, int chunk) {
         s.level = level; s.chunk = chunk;
         s.q_o = ws.queue_o[level & 1]; s.q_d = ws.queue_d[level & 1];
@@ -1016,6 +1013,11 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         return tstamp();
     };
     if (int rc = launch_traversal(0, 0, 0)) return rc;
+    if (fp.camera_only) {
+        RT_HIP_CHECK(hipGetLastError(), err);
+        *n_launches += launches;
+        return RT_OK;
+    }
     for (int level = 0; level <= fp.max_depth; level++) {
         const bool more = level < fp.max_depth;
         // chunk 0 also spawns the next level's rays; it runs even without lights
