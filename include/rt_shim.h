@@ -123,12 +123,14 @@ enum {
                                 the next build */
     RT_OPT_GRAPH = 7,        /* 1 (default): with RT_OPT_TIMING and RT_OPT_COUNT_TESTS off, a frame asked for twice in a row is captured as a hipGraph and replayed while nothing changes */
     RT_OPT_CLAIM_ORDER = 9   /* LBVH scenes, staged pipeline.  A traversal launch ends with its longest rays; when those start last the GPU
-                                idles behind them.  1 (default): the FIRST frame of a layout (frame size, rows, depth, light count, primitives
-                                set) is preceded by one counting pass of the same frame that records the longest ray of every 64-ray work
-                                unit; every later frame of that layout hands the units out longest first.  The order decides when a ray is
-                                traced, never what it hits: frames are bit-identical with it on or off, and a moved camera or refitted mesh
-                                keeps using it (it goes stale gracefully).  That first frame costs about three frames and the call waits
-                                for it (one host synchronisation).  0: off.  2: make a new order at the next frame (then back to 1). */
+                                idles behind them.  1 (default): when a layout (frame size, rows, depth, light count, primitives set) is
+                                asked for the second time in a row, that frame is preceded by one counting pass of the same frame that
+                                records the longest ray of every 64-ray work unit (and by two short timing runs that pick the camera-ray
+                                kernel); every later frame of that layout hands the units out longest first.  The order decides when a
+                                ray is traced, never what it hits: frames are bit-identical with it on or off, and a moved camera or
+                                refitted mesh keeps using it (it goes stale gracefully).  That one frame costs about three frames and the
+                                call waits for it (one host synchronisation); a caller that renders a single frame never pays it.
+                                0: off.  2: drop the order; the next repeating layout makes a new one (then back to 1). */
 };
 
 #define RT_MAX_ANALYTIC 1024

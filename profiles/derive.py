@@ -61,9 +61,11 @@ def main(argv):
     workload = argv[1] if len(argv) > 1 else "sponza"
     W, H = (int(argv[2]), int(argv[3])) if len(argv) > 3 else (1920, 1080)
     times, pl = load(d)
+    # frames = launches of the shading kernel; the counting frames among them (the pass that makes the claim order, bench.py's
+    # own counting frame) run the counting variants of the camera-ray kernels
     shade_calls = sum(c for k, (c, _) in times.items() if k.startswith("k_shade_all"))
-    cam = [c for k, (c, _) in times.items() if is_plain_traversal(k) and (k.startswith("k_trace_packet") or k.startswith("k_trace<0, true"))]
-    frames = max(cam) if cam else shade_calls
+    counting = sum(c for k, (c, _) in times.items() if (k.startswith("k_trace_packet<true") or k.startswith("k_trace<0, true, true")))
+    frames = max(shade_calls - counting, 1)
     print("frames with plain kernels in the trace pass: %d (of %d frames)" % (frames, shade_calls))
     kernels = {}
     fetch = wr = 0.0
@@ -72,6 +74,11 @@ def main(argv):
         if not is_plain_traversal(k):
             continue
         calls, avg_ns = times[k]
+        if 2 * calls < frames:
+            print("%-34s %d launches: the timing runs of the camera-ray kernel choice, not part of a frame" % (k, calls))
+            continue
+        if k.startswith("k_trace_packet") or k.startswith("k_trace<0, true"):
+            calls = min(calls, frames)          # one camera-ray launch per frame; any more are the timing runs of the kernel choice
         c = pl.get(k, {})
         insts = c.get("SQ_INSTS_VALU", 0.0)
         rec = {"launches_per_frame": calls / frames, "avg_us": avg_ns / 1e3}

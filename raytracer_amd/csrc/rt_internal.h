@@ -192,6 +192,7 @@ struct FrameWorkspace {
     bool order_valid = false;
     int camera_packet = 0;         // which camera-ray kernel was faster for this layout when the order was made
     std::vector<unsigned char> order_key;   // the frame layout unit_order was made for
+    std::vector<unsigned char> seen_key;    // the layout of the previous frame (an order is only made for a layout that repeats)
     // hit planes of the LBVH pipelines
     float2 *p_hits = nullptr;      // [levels][pixels] nearest (t, id bits)
     unsigned int *p_occ = nullptr; // [levels][chunks][pixels] occlusion bit per light, 32 lights per chunk

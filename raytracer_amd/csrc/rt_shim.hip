@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -462,8 +463,13 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         ok.W = W; ok.depth = max_depth; ok.n_lights = c->n_lights; ok.n_analytic = c->n_analytic; ok.n_tris = c->n_tris; ok.rows = *rows;
         ok.scene = c->scene_version;
         FrameWorkspace &ws = c->f->ws;
-        if (!ws.order_valid || ws.order_key.size() != sizeof ok || memcmp(ws.order_key.data(), &ok, sizeof ok) != 0) {
-            ws.order_valid = false;
+        const bool have = ws.order_valid && ws.order_key.size() == sizeof ok && memcmp(ws.order_key.data(), &ok, sizeof ok) == 0;
+        // An order is made when a layout is asked for the second time in a row (like the graph capture below): a caller
+        // that renders one frame, or never the same layout twice, pays nothing for it and runs in plain unit order.
+        const bool repeats = ws.seen_key.size() == sizeof ok && memcmp(ws.seen_key.data(), &ok, sizeof ok) == 0;
+        ws.seen_key.assign((const unsigned char *)&ok, (const unsigned char *)&ok + sizeof ok);
+        if (!have) ws.order_valid = false;
+        if (!have && repeats) {
             FrameParams cal = fp;
             cal.count_tests = 1; cal.timing = 0; cal.track_units = 1; cal.use_order = 0;
             const size_t n = ws.unit_stride * (size_t)ws.unit_launches;
@@ -525,9 +531,9 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
                 if (getenv("RT_WF_DEBUG")) fprintf(stderr, "[rt] camera rays: per-lane %.3f ms, packets %.3f ms -> %s\n", ms[0], ms[1], ws.camera_packet ? "packets" : "per-lane");
             }
         }
-        fp.use_order = 1;
+        fp.use_order = ws.order_valid ? 1 : 0;
     }
-    fp.camera_packet = c->opt_camera_packet >= 0 ? c->opt_camera_packet : ((wavefront && c->opt_claim_order) ? c->f->ws.camera_packet : 0);
+    fp.camera_packet = c->opt_camera_packet >= 0 ? c->opt_camera_packet : ((wavefront && fp.use_order) ? c->f->ws.camera_packet : 0);
     const bool want_graph = c->opt_graph && !fp.timing && !fp.count_tests;
     if (want_graph) {
         // The launches of a frame depend only on these values: when none changed since the last frame,
@@ -648,33 +654,39 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
         }
         base += (pl.bytes + 255) & ~(size_t)255;
     }
+    // One host thread copies ~9 GB/s, a fraction of what the bus delivers.  A large hand-over is therefore copied on by
+    // helper threads: this thread only waits for the pieces' events, in order, and publishes how many pieces have landed;
+    // helper k copies pieces k, k + HELPERS, ...  The helpers make no HIP call and are started before the frame has finished
+    // rendering, so their start-up costs nothing; until the first piece lands they sleep in short naps.
+    constexpr int HELPERS = 4;
+    const bool threaded = e == hipSuccess && staged >= ((size_t)2 << 20) && n_pieces >= HELPERS;
+    std::atomic<int> landed{ 0 };
+    std::atomic<bool> give_up{ false };
+    std::thread helpers[HELPERS];
+    if (threaded)
+        for (int k = 0; k < HELPERS; k++)
+            helpers[k] = std::thread([&pieces, &landed, &give_up, n_pieces, k] {
+                for (int q = k; q < n_pieces; q += HELPERS) {
+                    while (landed.load(std::memory_order_acquire) <= q) {
+                        if (give_up.load(std::memory_order_relaxed)) return;
+                        if (landed.load(std::memory_order_relaxed) == 0) std::this_thread::sleep_for(std::chrono::microseconds(30));
+                        else std::this_thread::yield();
+                    }
+                    memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
+                }
+            });
     // the frame itself first (the clock of staging_ms starts when the device has finished rendering)
     if (e == hipSuccess && c->f->frame_done) e = hipEventSynchronize(c->f->frame_done);
     const auto t0 = std::chrono::steady_clock::now();
-    // One host thread copies ~10 GB/s, a fifth of what the bus delivers: a large hand-over is copied on by four
-    // threads, thread k taking pieces k, k+4, ... as their events complete.
-    auto copy_on = [&pieces, n_pieces](int first, int stride, hipError_t *err) {
-        for (int q = first; q < n_pieces; q += stride) {
-            const hipError_t ee = hipEventSynchronize(pieces[q].ev);
-            if (ee != hipSuccess) { *err = ee; return; }
-            memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
-        }
-    };
-    if (e == hipSuccess && n_pieces > 0) {
-        constexpr int HELPERS = 3;
-        hipError_t errs[HELPERS + 1] = { hipSuccess, hipSuccess, hipSuccess, hipSuccess };
-        if (staged >= ((size_t)2 << 20) && n_pieces >= 2 * (HELPERS + 1)) {
-            std::thread helpers[HELPERS];
-            const int dev = c->device;
-            for (int k = 0; k < HELPERS; k++)
-                helpers[k] = std::thread([&, k, dev] { (void)hipSetDevice(dev); copy_on(k + 1, HELPERS + 1, &errs[k + 1]); });
-            copy_on(0, HELPERS + 1, &errs[0]);
-            for (std::thread &t : helpers) t.join();
-        } else {
-            copy_on(0, 1, &errs[0]);
-        }
-        for (hipError_t ee : errs)
-            if (e == hipSuccess) e = ee;
+    for (int q = 0; q < n_pieces && e == hipSuccess; q++) {
+        e = hipEventSynchronize(pieces[q].ev);
+        if (e != hipSuccess) break;
+        if (threaded) landed.store(q + 1, std::memory_order_release);
+        else memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
+    }
+    if (threaded) {
+        if (e != hipSuccess) give_up.store(true);
+        for (std::thread &t : helpers) t.join();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {

@@ -161,5 +161,5 @@ def test_bench_partitioned_job_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["frames_in_flight"] == single["config"]["frames_in_flight"] == 1
     assert d["config"]["rays_per_frame"] == single["config"]["rays_per_frame"]
-    assert d["value"] > 0 and abs(d["frame_latency_ms"] - d["ms_per_step"]) < 1e-9 and d["first_frame_ms"] > d["ms_per_step"]
+    assert d["value"] > 0 and abs(d["frame_latency_ms"] - d["ms_per_step"]) < 1e-9 and d["first_frame_ms"] > d["ms_per_step"] and d["order_frame_ms"] > d["ms_per_step"]
     assert d["pipelined"]["frames_in_flight"] == 4 and d["pipelined"]["value"] > 0 and single["pipelined"]["value"] > 0
