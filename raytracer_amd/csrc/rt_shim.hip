@@ -659,22 +659,35 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
     // helper k copies pieces k, k + HELPERS, ...  The helpers make no HIP call and are started before the frame has finished
     // rendering, so their start-up costs nothing; until the first piece lands they sleep in short naps.
     constexpr int HELPERS = 4;
-    const bool threaded = e == hipSuccess && staged >= ((size_t)2 << 20) && n_pieces >= HELPERS;
+    bool threaded = e == hipSuccess && staged >= ((size_t)2 << 20) && n_pieces >= HELPERS;
     std::atomic<int> landed{ 0 };
     std::atomic<bool> give_up{ false };
     std::thread helpers[HELPERS];
+    int started = 0;
     if (threaded)
-        for (int k = 0; k < HELPERS; k++)
-            helpers[k] = std::thread([&pieces, &landed, &give_up, n_pieces, k] {
-                for (int q = k; q < n_pieces; q += HELPERS) {
-                    while (landed.load(std::memory_order_acquire) <= q) {
-                        if (give_up.load(std::memory_order_relaxed)) return;
-                        if (landed.load(std::memory_order_relaxed) == 0) std::this_thread::sleep_for(std::chrono::microseconds(30));
-                        else std::this_thread::yield();
+        for (int k = 0; k < HELPERS; k++) {
+            try {
+                helpers[k] = std::thread([&pieces, &landed, &give_up, n_pieces, k] {
+                    for (int q = k; q < n_pieces; q += HELPERS) {
+                        while (landed.load(std::memory_order_acquire) <= q) {
+                            if (give_up.load(std::memory_order_relaxed)) return;
+                            if (landed.load(std::memory_order_relaxed) == 0) std::this_thread::sleep_for(std::chrono::microseconds(30));
+                            else std::this_thread::yield();
+                        }
+                        memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
                     }
-                    memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
-                }
-            });
+                });
+                started++;
+            } catch (...) {
+                break;      // no thread to be had: the helpers that did start are sent home, this thread copies everything
+            }
+        }
+    if (threaded && started < HELPERS) {
+        give_up.store(true);
+        for (int k = 0; k < started; k++) helpers[k].join();
+        give_up.store(false);
+        threaded = false;
+    }
     // the frame itself first (the clock of staging_ms starts when the device has finished rendering)
     if (e == hipSuccess && c->f->frame_done) e = hipEventSynchronize(c->f->frame_done);
     const auto t0 = std::chrono::steady_clock::now();

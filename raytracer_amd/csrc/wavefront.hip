@@ -203,9 +203,9 @@ void k_trace(TraceArgs A)
         // ---- refill idle lanes from the local range; claim a new unit when it is empty
         const unsigned long long idle = __ballot(node == NODE_SENTINEL);
         if (!exhausted && idle != 0ull && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
-            if (cur >= end) {
+            while (cur >= end && !exhausted) {
                 // units are dealt to shards round-robin (unit = k*n_shards + shard); a wave drains its own
-                // shard to the end, then steals from the next few
+                // shard to the end, then steals from the next few; an empty unit is followed by the next claim at once
                 unsigned int k = 0;
                 if (lane == 0) k = atomicAdd(&A.cursors[shard * CURSOR_STRIDE], 1u);
                 k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
@@ -239,10 +239,9 @@ void k_trace(TraceArgs A)
                 }
                 cur = region * REGION + sub * UNIT;
                 end = region * REGION + min(sub * UNIT + UNIT, cnt);
-                if (cur >= end) continue;      // empty unit
             }
             const unsigned int my = cur + (unsigned)__popcll(idle & lt);
-            if (COUNT) { dbg[4]++; dbg[5] += min((unsigned)__popcll(idle), end - cur); }
+            if (COUNT && cur < end) { dbg[4]++; dbg[5] += min((unsigned)__popcll(idle), end - cur); }
             if (node == NODE_SENTINEL && my < end) {
                 bool live = true;
                 const bool unit_any = MODE == 1 || (MODE == 2 && seg < A.n_segments);     // wave-uniform

@@ -1057,6 +1057,41 @@ def test_frame_slots_of_one_context_keep_frames_apart():
             ctx.render_rows_device(W, H, rt.RowSet(0, 1, 1, H), D, d_rgb8=pr.slots[0].local.data_ptr(), slot=rt.MAX_FRAME_SLOTS)
 
 
+def test_hierarchy_option_changed_with_frames_in_flight_on_other_slots():
+    """RT_OPT_LEAF_MAX changed between frames: the next frame rebuilds the hierarchy, freeing the nodes and the triangle
+    copy that frames already enqueued on other slots still read (and that their captured graphs point at).  The rebuild
+    has to wait for every slot first; every frame, before and after, must be the picture of its camera."""
+    import torch
+    from raytracer_amd.dist import PartitionedRenderer
+    spec = atrium_spec(detail=0.02)
+    W, H, D = 320, 200, 2
+    cams = [rt.Camera(origin=(0.3 * k - 0.3, -1.5 + 0.2 * k, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4) for k in range(3)]
+    with rt.Context(0) as ctx:
+        to_product(ctx, spec)
+        ctx.set_option(rt.OPT_TIMING, 0)
+        want = []
+        for cam in cams:
+            ctx.set_camera(cam)
+            want.append(ctx.render_frame(W, H, max_depth=D, want=("rgb8",))["rgb8"])
+        pr = PartitionedRenderer(ctx, W, H, D, frames_in_flight=3)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # every slot has replayed its graph at least once
+                for k in range(3):
+                    ctx.set_camera(cams[k])
+                    pr.render_async()
+            frames = []
+            for k in range(6):
+                ctx.set_camera(cams[k % 3])
+                if k == 4:
+                    ctx.set_option(rt.OPT_LEAF_MAX, 4)     # frames 0..3 are in flight; frame 4 rebuilds
+                frames.append(pr.render_async())
+            hosts = [f.wait().cpu().numpy().copy() for f in frames]
+        assert ctx.stats()["bvh_leaf_max"] == 4
+        for k, h in enumerate(hosts):
+            assert np.array_equal(h, want[k % 3]), k
+
+
 def _wires_and_walls_spec():
     """What whole-triangle boxes handle worst: long thin triangles that cross the scene diagonally, a huge
     two-triangle wall and floor, and small triangles scattered in the space their boxes cover."""
