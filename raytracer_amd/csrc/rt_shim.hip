@@ -457,7 +457,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
     if (wavefront && c->opt_claim_order && c->f->ws.unit_cost) {
         // The claim order of this frame layout: made once, by a counting frame that records every unit's longest ray, and
         // used by every later frame of the layout (a moved camera or refitted mesh keeps it: it only decides WHEN a ray
-        // is traced).  A new mesh or new analytic primitives (state_version) make a new one.
+        // is traced).  A new mesh or new analytic primitives (scene_version) make a new one.
         struct OrderKey { int W, depth, n_lights, n_analytic, n_tris; rt_rowset rows; unsigned long long scene; } ok;
         memset(&ok, 0, sizeof ok);
         ok.W = W; ok.depth = max_depth; ok.n_lights = c->n_lights; ok.n_analytic = c->n_analytic; ok.n_tris = c->n_tris; ok.rows = *rows;

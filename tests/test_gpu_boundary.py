@@ -210,3 +210,49 @@ def test_claim_order_changes_when_rays_are_traced_never_what_they_hit():
         on.set_option(rt.OPT_COUNT_TESTS, 1)
         assert same(frame(on), ref[1])
         assert on.stats()["box_tests"] > 0
+
+
+def test_camera_rays_as_packets_equal_the_per_lane_kernel(monkeypatch):
+    """k_trace_packet against k_trace for the camera rays (RT_WF_PACKET forces one of them when a context is created; left
+    alone, the faster of the two is picked per layout): hit ids, nearest t, float colour, 8-bit colour and ray counts must
+    be identical.  Frame widths that are no multiple of the 8-pixel tile, a camera whose rays leave through all eight
+    octants (tiles that straddle an axis take the minimum / maximum form of the box test), a band set of rows, an
+    irregular mesh, and a tree of single-triangle leaves."""
+    import torch
+    from common import soup_spec
+
+    def frame(ctx, W, H, D, rs):
+        n = rs.n_rows
+        rgb8 = torch.zeros((n, W, 3), dtype=torch.uint8, device="cuda")
+        hid = torch.zeros((n, W), dtype=torch.int32, device="cuda")
+        rgb32 = torch.zeros((n, W, 3), dtype=torch.float32, device="cuda")
+        ht = torch.zeros((n, W), dtype=torch.float32, device="cuda")
+        ctx.render_rows_device(W, H, rs, D, rgb8.data_ptr(), hid.data_ptr(), rgb32.data_ptr(), ht.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = ctx.stats()
+        return (rgb8.cpu().numpy(), hid.cpu().numpy(), rgb32.cpu().numpy().view(np.uint32), ht.cpu().numpy().view(np.uint32),
+                (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]))
+
+    cases = [
+        (atrium_spec(detail=0.05), 637, 403, 3, rt.Camera(origin=(0.0, -1.5, -6.0), pitch=8.0 / 637, off_x=-4.0, off_y=-3.4), None, 2),
+        (atrium_spec(detail=0.05), 640, 400, 2, rt.Camera(origin=(0.0, 0.0, 2.0), pitch=8.0 / 640, off_x=-4.0, off_y=-2.5, plane_z=3.0), (16, 1, 3), 2),
+        (soup_spec(n_tris=3000, seed=5), 322, 241, 2, rt.Camera(pitch=8.0 / 322), None, 1),
+    ]
+    for spec, W, H, D, cam, bands, leaf_max in cases:
+        rs = rt.band_rowset(H, bands[0], bands[1], bands[2]) if bands else rt.RowSet(0, 1, 1, H)
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("RT_WF_PACKET", mode)
+            with rt.Context(0) as ctx:
+                ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+                ctx.set_option(rt.OPT_LEAF_MAX, leaf_max)
+                to_product(ctx, spec)
+                ctx.set_camera(cam)
+                got[mode] = [frame(ctx, W, H, D, rs) for _ in range(3)]     # plain order, the order-making frame, ordered
+                assert ctx.stats()["accel"] == 1
+        monkeypatch.delenv("RT_WF_PACKET")
+        ref = got["0"][0]
+        assert (ref[1] >= 0).mean() > 0.2
+        for mode in ("0", "1"):
+            for f in got[mode]:
+                assert all(np.array_equal(x, y) for x, y in zip(f[:4], ref[:4])) and f[4] == ref[4], (mode, W, H)
