@@ -269,7 +269,15 @@ void k_trace(TraceArgs A)
                 }
                 if (live) {
                     best_t = FLT_MAX; best_id = -1;
-                    if (!unit_any) analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+                    if (PRIMARY) {
+                        analytic_nearest<COUNT>(sc, o, d, best_t, best_id, tl);
+                    } else if (!unit_any) {
+                        // a queued ray's nearest sphere / plane was found where the ray was made (k_shadow_gen, all 64 lanes
+                        // at work there) and waits in the hit plane this lane writes its result to
+                        const float2 h0 = A.hits[RTG(slot, A.n_pix)];
+                        best_t = h0.x; best_id = __float_as_int(h0.y);
+                        if (COUNT) tl.analytic += (unsigned)sc.n_analytic;
+                    }
                     slab_ray(sc.grid, o, d, inv, oi, sel_n, sel_f);
                     stack[0] = NODE_SENTINEL;
                     sp = 1;
@@ -726,6 +734,7 @@ struct ShadeArgs {
     float4 *sq_o;                     // [segment][slots_cap] (hit point, pixel)
     unsigned int *sq_counts;          // [segment][region]
     float4 *nq_o, *nq_d;              // next level's rays
+    float2 *next_hits;                // [pixel] hit plane of the next level: seeded with each new ray's nearest sphere / plane
     unsigned int *out_counts;         // next level's rays per region
     FrameCounters *counters;
 };
@@ -817,6 +826,12 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
                 const size_t dst = (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
                 A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
+                // the new ray's nearest analytic primitive (the first part of main.cpp:147-156), here with every lane busy
+                // instead of in the traversal's refill with a third of them: the traversal starts from this (t, id)
+                float bt = FLT_MAX;
+                int bid = -1;
+                analytic_nearest<false>(sc, pos, R, bt, bid, tl);
+                A.next_hits[r.pixel] = make_float2(bt, __int_as_float(bid));
             }
             if (threadIdx.x == 0) A.out_counts[region] = total;
         }
@@ -962,6 +977,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         s.occ = occ_of(level, chunk);
         s.nq_o = ws.queue_o[(level + 1) & 1]; s.nq_d = ws.queue_d[(level + 1) & 1];
         s.out_counts = ws.rq_counts[(level + 1) & 1];
+        s.next_hits = hits_of(level < fp.max_depth ? level + 1 : level);      // (nothing spawns at the last level)
         if (level == 0) hipLaunchKernelGGL(k_shadow_gen<true>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
         else hipLaunchKernelGGL(k_shadow_gen<false>, dim3(shade_grid), dim3(BLOCK), 0, stream, s);
         launches++;
