@@ -27,11 +27,12 @@ struct ShadeAllArgs {
 // stored in plane k.  Returns whether the chain goes on (main.cpp:208) and, if so, the next ray (pos, R).
 struct LevelOut { F3 col, pos, R, Mc; float kr; int id; bool spawn; };
 
-__device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p, int k, F3 o, F3 d, int &id0, unsigned int &n_shadow)
+// h, occ0: the level's hit and its first 32 occlusion bits, loaded by the caller (all levels' at once, ahead of the walk).
+__device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p, int k, F3 o, F3 d, int &id0, unsigned int &n_shadow, float2 h,
+                                                unsigned int occ0)
 {
     const DevScene &sc = A.sc;
     LevelOut out;
-    const float2 h = A.hits[(size_t)k * (size_t)A.n_pixels + p];
     const float t = h.x;
     int id = __float_as_int(h.y);
     if (id >= sc.n_analytic + sc.n_tris) id = -1;      // never index scene arrays with an id outside the scene
@@ -59,7 +60,7 @@ __device__ __forceinline__ LevelOut shade_level(const ShadeAllArgs &A, size_t p,
             n_shadow += (unsigned)sc.n_lights;
             unsigned int bits = 0;
             for (int li = 0; li < sc.n_lights; li++) {                            // main.cpp:170-173
-                if ((li & 31) == 0) bits = A.occ[((size_t)k * A.n_chunks + (li >> 5)) * (size_t)A.n_pixels + p];
+                if ((li & 31) == 0) bits = li == 0 ? occ0 : A.occ[((size_t)k * A.n_chunks + (li >> 5)) * (size_t)A.n_pixels + p];
                 const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
                 const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));     // main.cpp:178
                 const float shade = ((bits >> (li & 31)) & 1u) ? 0.0f : 1.0f;     // main.cpp:175, 185
@@ -97,11 +98,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
             F3 lc[NL], lm[NL];
             float lk[NL];
             bool alive = true;
+            // Every level's hit and occlusion word of this pixel, requested at once: the walk below would otherwise wait
+            // for them one level at a time, each behind the previous level's arithmetic.  (Planes of levels the chain does
+            // not reach hold an earlier frame's values: read, never used.)
+            float2 hk[NL];
+            unsigned int ok[NL];
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const bool in = k <= A.max_depth;
+                hk[k] = in ? A.hits[(size_t)k * (size_t)A.n_pixels + p] : make_float2(FLT_MAX, __int_as_float(-1));
+                ok[k] = (in && sc.n_lights > 0) ? A.occ[(size_t)k * A.n_chunks * (size_t)A.n_pixels + p] : 0u;
+            }
 #pragma unroll
             for (int k = 0; k < NL; k++) {
                 lc[k] = mk(0.f, 0.f, 0.f); lm[k] = mk(0.f, 0.f, 0.f); lk[k] = 0.f;
                 if (alive) {
-                    const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow);
+                    const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow, hk[k], ok[k]);
                     lc[k] = L.col; lm[k] = L.Mc; lk[k] = L.kr;
                     last = k;
                     alive = L.spawn;
@@ -117,7 +129,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_all(ShadeAllArgs A)
             }
         } else {
             for (int k = 0;; k++) {
-                const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow);
+                const LevelOut L = shade_level(A, p, k, o, d, id0, n_shadow, A.hits[(size_t)k * (size_t)A.n_pixels + p],
+                                               sc.n_lights > 0 ? A.occ[(size_t)k * A.n_chunks * (size_t)A.n_pixels + p] : 0u);
                 last = k;
                 A.records[(size_t)k * (size_t)A.n_pixels + p] = make_float4(L.col.x, L.col.y, L.col.z, __int_as_float(L.id));
                 if (!L.spawn) break;
