@@ -777,32 +777,19 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
     return r;
 }
 
-// Rank of this thread among the block's threads with `flag` set, and the block total.
-// s_cnt: 4 LDS words.  Two barriers; every thread of the block must call it.
-__device__ __forceinline__ unsigned int block_rank(bool flag, unsigned int *s_cnt, unsigned int &total)
-{
-    const unsigned long long mask = __ballot(flag);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) s_cnt[wave] = (unsigned)__popcll(mask);
-    __syncthreads();
-    unsigned int before = 0, all = 0;
-    for (int w = 0; w < BLOCK / 64; w++) {
-        const unsigned int c = s_cnt[w];
-        if (w < wave) before += c;
-        all += c;
-    }
-    __syncthreads();
-    total = all;
-    return before + (unsigned)__popcll(mask & lanemask_lt());
-}
-
 template <bool PRIMARY>
 __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
 {
-    __shared__ unsigned int s_cnt[BLOCK / 64];
+    // [list][wave] rays each wave of the block contributes to every output list of the region: lists 0..31 = the shadow
+    // queues of the chunk's lights, list 32 = the next level's ray queue.  All lists are ranked behind ONE barrier
+    // (one barrier per list made a region wait seven times where it now waits twice).
+    constexpr int WAVES = BLOCK / 64, LISTS = 33;
+    __shared__ unsigned int s_cnt[LISTS][WAVES];
     const DevScene &sc = A.sc;
     Tally tl = { 0u, 0u, 0u };
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long lt = lanemask_lt();
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
         const unsigned int cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
@@ -810,19 +797,44 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
         bool lit = r.live && r.id >= 0;
         if (lit && r.id < sc.n_analytic && sc.analytic[r.id].is_light) lit = false;       // main.cpp:166
         const F3 pos = add(r.o, muls(r.d, r.t));                                          // main.cpp:163
-        if (A.chunk == 0) {
-            // the next level's ray (main.cpp:208-211) leaves here, before the shadow rays are traced:
-            // it does not depend on them, and the two kinds of ray share the next traversal launch
-            bool spawn = false;
-            F3 R = r.d;
-            if (lit && A.level < A.max_depth) {
-                const Surface s = surface_at(sc, r.id, pos, r.o, r.d);                             // main.cpp:164
-                spawn = s.kr > 0.0f;                                                      // main.cpp:208
-                if (spawn) R = mirror_dir(r.d, s.N);                                      // main.cpp:210
+        // the next level's ray (main.cpp:208-211) leaves here, before the shadow rays are traced:
+        // it does not depend on them, and the two kinds of ray share the next traversal launch
+        bool spawn = false;
+        F3 R = r.d;
+        if (A.chunk == 0 && lit && A.level < A.max_depth) {
+            const Surface s = surface_at(sc, r.id, pos, r.o, r.d);                        // main.cpp:164
+            spawn = s.kr > 0.0f;                                                          // main.cpp:208
+            if (spawn) R = mirror_dir(r.d, s.N);                                          // main.cpp:210
+        }
+        // per light: blocked by a sphere or plane already (bit set), or a shadow ray to be traced (want)
+        unsigned int bits = 0, want = 0;
+        for (int li = l0; li < l1; li++) {                                                // main.cpp:170-173
+            if (lit) {
+                const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
+                const F3 L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));             // main.cpp:178
+                const F3 so = add(pos, muls(L, 0.01f));                                   // main.cpp:179
+                if (analytic_occluded<false>(sc, so, L, tl)) bits |= 1u << (li - l0);
+                else want |= 1u << (li - l0);
             }
-            unsigned int total;
-            const unsigned int rank = block_rank(spawn, s_cnt, total);
+        }
+        // ---- ranks: every wave's count per list, one barrier, then each ray's place = waves before + lanes before
+        const unsigned long long m_spawn = __ballot(spawn);
+        if ((threadIdx.x & 63) == 0) s_cnt[32][wave] = (unsigned)__popcll(m_spawn);
+        for (int li = l0; li < l1; li++) {
+            const unsigned long long m = __ballot((want >> (li - l0)) & 1u);
+            if ((threadIdx.x & 63) == 0) s_cnt[li - l0][wave] = (unsigned)__popcll(m);
+        }
+        __syncthreads();
+        if (A.chunk == 0) {
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                const unsigned int c = s_cnt[32][w];
+                if (w < wave) before += c;
+                total += c;
+            }
             if (spawn) {
+                const unsigned int rank = before + (unsigned)__popcll(m_spawn & lt);
                 const size_t dst = (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
                 A.nq_o[dst] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));  // origin is pos itself (main.cpp:211)
                 A.nq_d[dst] = make_float4(R.x, R.y, R.z, 0.f);
@@ -835,26 +847,25 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             }
             if (threadIdx.x == 0) A.out_counts[region] = total;
         }
-        unsigned int bits = 0;
-        for (int li = l0; li < l1; li++) {                                                // main.cpp:170-173
-            const DevAnalytic lt_ = sc.analytic[sc.lights[li]];
-            bool want = false;
-            F3 L = mk(0.f, 0.f, 1.f), so = pos;
-            if (lit) {
-                L = normalize(sub(mk(lt_.px, lt_.py, lt_.pz), pos));                       // main.cpp:178
-                so = add(pos, muls(L, 0.01f));                                            // main.cpp:179
-                if (analytic_occluded<false>(sc, so, L, tl)) bits |= 1u << (li - l0);
-                else want = true;
+        for (int li = l0; li < l1; li++) {
+            const bool mine = (want >> (li - l0)) & 1u;
+            const unsigned long long m = __ballot(mine);
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                const unsigned int c = s_cnt[li - l0][w];
+                if (w < wave) before += c;
+                total += c;
             }
-            unsigned int total;
-            const unsigned int rank = block_rank(want, s_cnt, total);
-            if (want) {
+            if (mine) {
+                const unsigned int rank = before + (unsigned)__popcll(m & lt);
                 const size_t q = (size_t)(li - l0) * A.slots_cap + (size_t)RTG((size_t)region * REGION + rank, A.slots_cap);
-                A.sq_o[q] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));      // the traversal forms L and the origin again
+                A.sq_o[q] = make_float4(pos.x, pos.y, pos.z, __int_as_float(r.pixel));    // the traversal forms L and the origin again
             }
             if (threadIdx.x == 0) A.sq_counts[(size_t)(li - l0) * A.n_regions + region] = total;
         }
         if (r.live && l1 > l0) A.occ[r.pixel] = bits;
+        __syncthreads();        // the counts are read; the next region may overwrite them
     }
 }
 
