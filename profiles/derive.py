@@ -30,9 +30,14 @@ def short(name):
     return name.split("(")[0][:60]
 
 
+def newest(files):
+    # a directory merged from several collections holds one file per collection: only the last one counts
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 def load(d):
     times = {}
-    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             times[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
     counters = defaultdict(lambda: defaultdict(float))
@@ -40,7 +45,7 @@ def load(d):
     for p in sorted(glob.glob(os.path.join(d, "pmc*"))):
         if not os.path.isdir(p):
             continue
-        for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True)):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 counters[k][r["Counter_Name"]] += float(r["Counter_Value"])
