@@ -751,11 +751,31 @@ __device__ __forceinline__ unsigned int region_count(const ShadeArgs &A, int reg
     return A.in_counts[region];
 }
 
+// A region's queue entries as they lie in memory, asked for one region ahead of their use: a block walks its regions in a
+// loop whose body is a chain of dependent loads (count -> ray -> hit -> surface -> material), and the first two links
+// of the next region's chain cost nothing while the current region is worked on.  Entries past the region's count are
+// read too (they lie inside the queue) and ignored.
+struct SlotFetch { float4 qo, qd; unsigned int cnt; };
+
 template <bool PRIMARY>
-__device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int slot, bool in_range)
+__device__ __forceinline__ SlotFetch fetch_slot(const ShadeArgs &A, int region)
+{
+    SlotFetch f;
+    f.qo = f.qd = make_float4(0.f, 0.f, 1.f, 0.f);
+    f.cnt = 0;
+    if (region < A.n_regions) {
+        f.cnt = region_count<PRIMARY>(A, region);
+        const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
+        if (!PRIMARY && slot < A.slots_cap) { f.qo = A.q_o[slot]; f.qd = A.q_d[slot]; }
+    }
+    return f;
+}
+
+template <bool PRIMARY>
+__device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int slot, const SlotFetch &f)
 {
     SlotRay r;
-    r.live = in_range;
+    r.live = threadIdx.x < f.cnt;
     r.pixel = 0; r.t = FLT_MAX; r.id = -1;
     r.o = mk(0.f, 0.f, 0.f); r.d = mk(0.f, 0.f, 1.f);
     if (r.live) {
@@ -763,8 +783,7 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
             const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, slot);
             r.o = pr.o; r.d = pr.d; r.pixel = pr.pixel; r.live = pr.live;
         } else {
-            const float4 qo = A.q_o[RTG(slot, A.slots_cap)], qd = A.q_d[RTG(slot, A.slots_cap)];
-            r.o = f3(qo); r.d = f3(qd); r.pixel = __float_as_int(qo.w);
+            r.o = f3(f.qo); r.d = f3(f.qd); r.pixel = __float_as_int(f.qo.w);
         }
     }
     if (r.live) {
@@ -790,10 +809,11 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
     const int l0 = A.chunk * 32, l1 = min(sc.n_lights, l0 + 32);
     const int wave = threadIdx.x >> 6;
     const unsigned long long lt = lanemask_lt();
+    SlotFetch ahead = fetch_slot<PRIMARY>(A, (int)blockIdx.x);
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
-        const unsigned int cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
-        const SlotRay r = load_slot<PRIMARY>(A, slot, threadIdx.x < cnt);
+        const SlotRay r = load_slot<PRIMARY>(A, slot, ahead);
+        ahead = fetch_slot<PRIMARY>(A, region + (int)gridDim.x);
         bool lit = r.live && r.id >= 0;
         if (lit && r.id < sc.n_analytic && sc.analytic[r.id].is_light) lit = false;       // main.cpp:166
         const F3 pos = add(r.o, muls(r.d, r.t));                                          // main.cpp:163

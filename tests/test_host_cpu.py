@@ -28,6 +28,13 @@ def test_library_exports_every_declared_symbol():
     assert version == rt.ABI_VERSION
 
 
+def test_build_entry_point_accepts_the_libraries_in_the_tree():
+    # the part of __graft_entry__.build() after the compile: both libraries load, export every entry point and report
+    # the ABI version of the Python host
+    import __graft_entry__ as entry
+    entry.check_libraries()
+
+
 def test_struct_layouts_match_the_header():
     # sizes the C side assumes (include/rt_shim.h); a mismatch would corrupt every call
     assert ctypes.sizeof(rt.Material) == 24
