@@ -766,7 +766,7 @@ __device__ __forceinline__ SlotFetch fetch_slot(const ShadeArgs &A, int region)
     if (region < A.n_regions) {
         f.cnt = region_count<PRIMARY>(A, region);
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
-        if (!PRIMARY && slot < A.slots_cap) { f.qo = A.q_o[slot]; f.qd = A.q_d[slot]; }
+        if (!PRIMARY && slot < A.slots_cap) { f.qo = A.q_o[RTG(slot, A.slots_cap)]; f.qd = A.q_d[RTG(slot, A.slots_cap)]; }
     }
     return f;
 }
