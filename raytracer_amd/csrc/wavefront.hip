@@ -771,8 +771,26 @@ __device__ __forceinline__ SlotFetch fetch_slot(const ShadeArgs &A, int region)
     return f;
 }
 
+// The third link of the chain, asked for once the entry it depends on has landed (in the middle of the previous
+// region's work): the nearest hit of the entry's ray, from the hit plane of its pixel.
 template <bool PRIMARY>
-__device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int slot, const SlotFetch &f)
+__device__ __forceinline__ float2 fetch_hit(const ShadeArgs &A, int region, const SlotFetch &f)
+{
+    float2 h = make_float2(FLT_MAX, __int_as_float(-1));
+    if (region < A.n_regions && threadIdx.x < f.cnt) {
+        int pixel = __float_as_int(f.qo.w);
+        bool live = true;
+        if (PRIMARY) {
+            const PixelRay pr = primary_ray(A.cam, A.W, A.n_rows, A.rows, (unsigned)region * REGION + threadIdx.x);
+            pixel = pr.pixel; live = pr.live;
+        }
+        if (live) h = A.hits[RTG(pixel, A.n_pixels)];
+    }
+    return h;
+}
+
+template <bool PRIMARY>
+__device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int slot, const SlotFetch &f, float2 h)
 {
     SlotRay r;
     r.live = threadIdx.x < f.cnt;
@@ -788,7 +806,6 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
     }
     if (r.live) {
         r.pixel = (int)RTG(r.pixel, A.n_pixels);
-        const float2 h = A.hits[r.pixel];
         r.t = h.x; r.id = __float_as_int(h.y);
         // never index scene arrays with an id outside the scene
         if (r.id >= A.sc.n_analytic + A.sc.n_tris) r.id = -1;
@@ -797,7 +814,7 @@ __device__ __forceinline__ SlotRay load_slot(const ShadeArgs &A, unsigned int sl
 }
 
 template <bool PRIMARY>
-__global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_gen(ShadeArgs A)
 {
     // [list][wave] rays each wave of the block contributes to every output list of the region: lists 0..31 = the shadow
     // queues of the chunk's lights, list 32 = the next level's ray queue.  All lists are ranked behind ONE barrier
@@ -810,9 +827,10 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
     const int wave = threadIdx.x >> 6;
     const unsigned long long lt = lanemask_lt();
     SlotFetch ahead = fetch_slot<PRIMARY>(A, (int)blockIdx.x);
+    float2 hit_ahead = fetch_hit<PRIMARY>(A, (int)blockIdx.x, ahead);
     for (int region = blockIdx.x; region < A.n_regions; region += gridDim.x) {
         const unsigned int slot = (unsigned)region * REGION + threadIdx.x;
-        const SlotRay r = load_slot<PRIMARY>(A, slot, ahead);
+        const SlotRay r = load_slot<PRIMARY>(A, slot, ahead, hit_ahead);
         ahead = fetch_slot<PRIMARY>(A, region + (int)gridDim.x);
         bool lit = r.live && r.id >= 0;
         if (lit && r.id < sc.n_analytic && sc.analytic[r.id].is_light) lit = false;       // main.cpp:166
@@ -826,6 +844,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_gen(ShadeArgs A)
             spawn = s.kr > 0.0f;                                                          // main.cpp:208
             if (spawn) R = mirror_dir(r.d, s.N);                                          // main.cpp:210
         }
+        hit_ahead = fetch_hit<PRIMARY>(A, region + (int)gridDim.x, ahead);                // (its entry has landed by now)
         // per light: blocked by a sphere or plane already (bit set), or a shadow ray to be traced (want)
         unsigned int bits = 0, want = 0;
         for (int li = l0; li < l1; li++) {                                                // main.cpp:170-173
