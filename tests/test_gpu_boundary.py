@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from common import atrium_spec, cube_spec, rt, to_product
+from common import atrium_spec, compare, cube_spec, ocam, rt, to_oracle, to_product
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -256,3 +256,71 @@ def test_camera_rays_as_packets_equal_the_per_lane_kernel(monkeypatch):
         for mode in ("0", "1"):
             for f in got[mode]:
                 assert all(np.array_equal(x, y) for x, y in zip(f[:4], ref[:4])) and f[4] == ref[4], (mode, W, H)
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_scenes_through_every_staged_kernel_choice_equal_the_oracle(seed, monkeypatch):
+    """Seeded random frames: triangle count, leaf size, depth, frame size (any width and height, not tile multiples), a
+    camera anywhere in or around the mesh with its window anywhere (so rays leave through every octant and some run
+    parallel to an axis), one to three lights.  The oracle's brute-force scan is the reference; the staged pipeline must
+    match it with the camera rays on the per-lane kernel and on packets, on the first frame of the layout, the
+    order-making frame and an ordered frame."""
+    import torch
+    from common import soup_spec, sphere
+
+    r = np.random.default_rng(4000 + seed).random(16)        # (the frame is compared with an oracle frame made here, from the same draw)
+    n_tris = int(2 + r[0] ** 3 * 6000)
+    W, H = int(1 + r[1] * 150), int(1 + r[2] * 110)
+    D = int(r[3] * 6)
+    leaf_max = (1, 2, 4, 8)[int(r[4] * 4)]
+    spec = soup_spec(n_tris=n_tris, seed=31 * seed + 5)
+    if r[5] < 0.5:                                # a third light inside the mesh
+        spec.analytic.append(sphere((float(r[6] * 6 - 3), float(r[7] * 4 - 2), float(r[8] * 6)), 0.05, (0.0, 1.0, 1.0, (0.5, 0.9, 0.6)), True))
+    if seed % 4 == 3:                             # a single light
+        spec.analytic = [a for k, a in enumerate(spec.analytic) if k != 2]
+    origin = (float(r[9] * 10 - 5), float(r[10] * 6 - 3), float(r[11] * 10 - 6))
+    span = 2.0 + r[12] * 10.0
+    pitch = span / max(W, H)
+    # a window that straddles the axis through the origin in x and y puts rays with a zero direction component on it
+    cam = rt.Camera(origin=origin, pitch=pitch, off_x=origin[0] - pitch * int(W * r[13]), off_y=origin[1] - pitch * int(H * r[14]),
+                    plane_z=origin[2] + (1.0 if r[15] < 0.7 else -1.0))
+    want = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam), threads=16)
+    rs = rt.RowSet(0, 1, 1, H)
+
+    def frame(ctx):
+        rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        hid = torch.full((H, W), -7, dtype=torch.int32, device="cuda")
+        rgb32 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        ctx.render_rows_device(W, H, rs, D, rgb8.data_ptr(), hid.data_ptr(), rgb32.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = ctx.stats()
+        return dict(rgb8=rgb8.cpu().numpy(), hit_id=hid.cpu().numpy(), rgb32=rgb32.cpu().numpy()), (st["rays_primary"], st["rays_shadow"], st["rays_reflect"])
+
+    def orays(o):
+        return (o["counts"]["primary"], o["counts"]["shadow"], o["counts"]["reflect"])
+
+    def assert_parity(c):
+        # ids identical; 8-bit colour within 1/255 everywhere and equal on >= 99.9 % of the pixels; float colour within powf's ulps
+        assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0 and c["rgb8_exact"] >= 0.999 * c["pixels"] and c["rgb32_max_abs"] <= 4e-6, (seed, c)
+
+    first = None
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RT_WF_PACKET", mode)
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+            ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_WAVEFRONT)
+            ctx.set_option(rt.OPT_LEAF_MAX, leaf_max)
+            to_product(ctx, spec)
+            ctx.set_camera(cam)
+            for k in range(3):
+                g, counts = frame(ctx)
+                if first is None:
+                    first = g
+                    assert_parity(compare(g, want))
+                    assert counts == orays(want), (seed, counts, orays(want))
+                else:
+                    for key in ("rgb8", "hit_id", "rgb32"):
+                        assert np.array_equal(g[key].view(np.uint8), first[key].view(np.uint8)), (seed, mode, k, key)
+                    assert counts == orays(want)
+            assert ctx.stats()["accel"] == 1
+    monkeypatch.delenv("RT_WF_PACKET")
