@@ -140,12 +140,18 @@ def host_frame_times(ctx, wl, steps):
     for name, buf in (("host_frame_ms", image), ("host_frame_pinned_ms", pinned)):
         for _ in range(2):
             ctx.render_frame_into(wl.W, wl.H, buf, max_depth=wl.max_depth)
-        t0 = time.perf_counter()
+        walls, after = [], []
         for _ in range(steps):
+            t0 = time.perf_counter()
             ctx.render_frame_into(wl.W, wl.H, buf, max_depth=wl.max_depth)
-        out[name] = (time.perf_counter() - t0) / steps * 1e3
+            walls.append((time.perf_counter() - t0) * 1e3)
+            after.append(ctx.stats()["staging_ms"])
+        # a synchronous call per frame: the median (one call in a few dozen takes milliseconds longer on a busy host),
+        # with the mean beside it
+        out[name] = float(np.median(walls))
+        out[name.replace("_ms", "_mean_ms")] = float(np.mean(walls))
         # of which, after the device finished the frame: copies into the staging buffer and on into the array / the one copy
-        out[name.replace("_ms", "_handover_ms")] = ctx.stats()["staging_ms"]
+        out[name.replace("_ms", "_handover_ms")] = float(np.median(after))
     ctx.free_host_buffer(pinned)
     return out
 

@@ -76,7 +76,8 @@ struct FrameSlot {
     hipStream_t last_stream = nullptr;
 };
 
-constexpr int HOST_PIECES = 8;     // pieces a plane of a host hand-over is cut into (piece k+1 flies while piece k is copied on)
+constexpr int HOST_PIECES = 8;     // most pieces a plane of a host hand-over is cut into (piece k+1 flies while piece k is copied on)
+constexpr int HOST_PIECES_DEFAULT = 4;   // measured on a 6.2 MB plane: 1 piece 0.29 ms after the frame, 2: 0.25, 3-4: 0.23, 6: 0.26, 8: 0.28 (each piece costs ~15 us)
 constexpr int HOST_PLANES_MAX = 6; // planes of rt_frame_planes
 
 struct rt_ctx {
@@ -615,7 +616,7 @@ bool host_range_pinned(const rt_ctx *c, const void *p, size_t bytes)
 // Device planes into the caller's host buffers, behind the frame on the context's stream; returns when they are there.
 // A plane inside a buffer of rt_alloc_host_buffer is written by the device directly.  Any other buffer is
 // pageable: a device copy into it would go through the runtime's own bounce buffer at a fraction of the bus rate, so
-// such a plane goes into the context's pinned staging buffer in HOST_PIECES pieces, an event behind each, and the host
+// such a plane goes into the context's pinned staging buffer in a few pieces (HOST_PIECES_DEFAULT), an event behind each, and the host
 // copies piece k on into the caller's buffer while the later pieces are still in flight.
 int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
 {
@@ -642,7 +643,8 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
             continue;
         }
         // small planes go in one piece; pieces are multiples of 4 KiB
-        const int want = pl.bytes >= ((size_t)1 << 20) ? HOST_PIECES : 1;
+        static const int pieces_env = getenv("RT_HOST_PIECES") ? atoi(getenv("RT_HOST_PIECES")) : 0;   // (measurements)
+        const int want = pl.bytes >= ((size_t)1 << 20) ? (pieces_env >= 1 && pieces_env <= HOST_PIECES ? pieces_env : HOST_PIECES_DEFAULT) : 1;
         const size_t step = ((pl.bytes + want - 1) / want + 4095) & ~(size_t)4095;
         for (size_t off = 0; off < pl.bytes && e == hipSuccess; off += step) {
             const size_t n = off + step <= pl.bytes ? step : pl.bytes - off;
@@ -656,10 +658,10 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
     }
     // One host thread copies ~9 GB/s, a fraction of what the bus delivers.  A large hand-over is therefore copied on by
     // helper threads: this thread only waits for the pieces' events, in order, and publishes how many pieces have landed;
-    // helper k copies pieces k, k + HELPERS, ...  The helpers make no HIP call and are started before the frame has finished
+    // every helper copies its share of each landed piece.  The helpers make no HIP call and are started before the frame has finished
     // rendering, so their start-up costs nothing; until the first piece lands they sleep in short naps.
     constexpr int HELPERS = 4;
-    bool threaded = e == hipSuccess && staged >= ((size_t)2 << 20) && n_pieces >= HELPERS;
+    bool threaded = e == hipSuccess && staged >= ((size_t)2 << 20);
     std::atomic<int> landed{ 0 };
     std::atomic<bool> give_up{ false };
     std::thread helpers[HELPERS];
@@ -668,13 +670,20 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
         for (int k = 0; k < HELPERS; k++) {
             try {
                 helpers[k] = std::thread([&pieces, &landed, &give_up, n_pieces, k] {
-                    for (int q = k; q < n_pieces; q += HELPERS) {
+                    for (int q = 0; q < n_pieces; q++) {
                         while (landed.load(std::memory_order_acquire) <= q) {
                             if (give_up.load(std::memory_order_relaxed)) return;
                             if (landed.load(std::memory_order_relaxed) == 0) std::this_thread::sleep_for(std::chrono::microseconds(30));
                             else std::this_thread::yield();
                         }
-                        memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
+                        // every helper takes its quarter of every piece (whole 4 KiB pages), so the last piece - the only one
+                        // whose copy nothing hides - is copied at all helpers' rate
+                        const size_t part = ((pieces[q].bytes + HELPERS - 1) / HELPERS + 4095) & ~(size_t)4095;
+                        const size_t lo = (size_t)k * part;
+                        if (lo < pieces[q].bytes) {
+                            const size_t n = lo + part <= pieces[q].bytes ? part : pieces[q].bytes - lo;
+                            memcpy((unsigned char *)pieces[q].dst + lo, pieces[q].src + lo, n);
+                        }
                     }
                 });
                 started++;
