@@ -105,7 +105,8 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     # multigpu.cpp calls the HIP runtime and RCCL directly (streams, buffers, the all-gather of the slices)
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include")] + srcs + [
+    # (plain g++: the HIP headers want to be told the platform, as hipcc tells them)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__=1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include")] + srcs + [
         "-o", HOST_BIN, "-L", HERE, "-lrt_amd", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
         "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE, "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:

@@ -546,7 +546,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         memcpy(&key.fp, &fp, sizeof fp); memcpy(&key.sc, &sc, sizeof sc); key.cam = c->cam;
         key.out[0] = d_rgb8; key.out[1] = d_hit_id; key.out[2] = d_rgb32; key.out[3] = d_hit_t;
         void *wsp[16] = { c->f->ws.records, c->f->ws.queue_o[0], c->f->ws.queue_o[1], c->f->ws.queue_d[0], c->f->ws.queue_d[1], c->f->ws.counters,
-                          c->f->ws.p_hits, c->f->ws.p_occ, c->f->ws.sq_o, nullptr, c->f->ws.trace_cursors, c->f->ws.overflow,
+                          c->f->ws.p_hits, c->f->ws.p_occ, c->f->ws.sq_o, c->f->ws.unit_order, c->f->ws.trace_cursors, c->f->ws.overflow,
                           c->f->ws.rq_counts[0], c->f->ws.rq_counts[1], c->f->ws.sq_counts, c->f->ws.hit_t };
         memcpy(key.ws, wsp, sizeof wsp);
         key.version = c->state_version;

@@ -1,6 +1,5 @@
 // multigpu.cpp — see multigpu.h.  RCCL is called directly (ncclCommInitAll: one process, one communicator rank
 // per device); no collective besides the one all-gather of the 8-bit slices.
-#define __HIP_PLATFORM_AMD__ 1
 #include "multigpu.h"
 
 #include <hip/hip_runtime_api.h>
