@@ -158,7 +158,7 @@ def host_frame_times(ctx, wl, steps):
 
 def measured_valu(workload, world, resolution):
     """Issue utilisation, mean active lanes and the FMA / MUL / ADD share of the traversal kernels from the committed
-    counter passes (profiles/valu_counters.json, written by profiles/summarize.py); like the traffic figure it is only
+    counter passes (profiles/valu_counters.json, written by profiles/derive.py); like the traffic figure it is only
     reported for exactly the kernel sources, workload and frame size it was measured on."""
     from raytracer_amd.build import source_hash
     try:
@@ -174,7 +174,7 @@ def measured_valu(workload, world, resolution):
 
 def measured_traffic(workload, world, resolution):
     """HBM-side bytes per frame of the traversal kernel from the committed counter passes
-    (profiles/hbm_traffic.json, written by profiles/hbm_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
+    (profiles/hbm_traffic.json, written by profiles/derive.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
     runs).  Counters cannot be read inside this process, so the figure is only reported when the file was
     measured on exactly these kernel sources (its source_hash equals the tree's); otherwise null."""
     from raytracer_amd.build import source_hash

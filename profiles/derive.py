@@ -55,8 +55,8 @@ def load(d):
 
 
 def is_plain_traversal(k):
-    # the non-counting variants: k_trace<mode, primary, false>, k_trace_packet<false>
-    return (k.startswith("k_trace<") or k.startswith("k_trace_packet<")) and k.rstrip(">").endswith("false")
+    # the non-counting variants: k_trace<mode, primary, 0>, k_trace_packet<0>
+    return (k.startswith("k_trace<") and k.endswith(", 0>")) or k.startswith("k_trace_packet<0>")
 
 
 def main(argv):
@@ -66,10 +66,10 @@ def main(argv):
     workload = argv[1] if len(argv) > 1 else "sponza"
     W, H = (int(argv[2]), int(argv[3])) if len(argv) > 3 else (1920, 1080)
     times, pl = load(d)
-    # frames = launches of the shading kernel; the counting frames among them (the pass that makes the claim order, bench.py's
-    # own counting frame) run the counting variants of the camera-ray kernels
+    # frames = launches of the shading kernel; the counting frames among them (bench.py's own counting frame) run the
+    # counting variants <.., 1> of the camera-ray kernels (the pass that makes the claim order, <.., 2>, does not shade)
     shade_calls = sum(c for k, (c, _) in times.items() if k.startswith("k_shade_all"))
-    counting = sum(c for k, (c, _) in times.items() if (k.startswith("k_trace_packet<true") or k.startswith("k_trace<0, true, true")))
+    counting = sum(c for k, (c, _) in times.items() if (k.startswith("k_trace_packet<1>") or k.startswith("k_trace<0, true, 1>")))
     frames = max(shade_calls - counting, 1)
     print("frames with plain kernels in the trace pass: %d (of %d frames)" % (frames, shade_calls))
     kernels = {}

@@ -150,7 +150,7 @@ struct FrameParams {
     int W, H;
     rt_rowset rows;
     int max_depth;
-    int count_tests;
+    int count_tests;               // 1: count tests and lane statistics (slow kernels); 2: only record the claim units' costs (track_units), no picture
     int timing;
     int stack_depth;               // LBVH depth bound used to pick the traversal variant
     int wide_depth;                // depth of the 4-wide tree

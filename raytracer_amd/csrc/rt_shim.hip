@@ -472,7 +472,7 @@ int render_common(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth,
         if (!have) ws.order_valid = false;
         if (!have && repeats) {
             FrameParams cal = fp;
-            cal.count_tests = 1; cal.timing = 0; cal.track_units = 1; cal.use_order = 0;
+            cal.count_tests = 2; cal.timing = 0; cal.track_units = 1; cal.use_order = 0;
             const size_t n = ws.unit_stride * (size_t)ws.unit_launches;
             if (hipMemsetAsync(ws.unit_cost, 0, sizeof(unsigned int) * n, stream) != hipSuccess) return fail(RT_E_DEVICE, "clear unit costs");
             int cal_launches = 0;

@@ -118,11 +118,14 @@ struct TraceArgs {
 // MODE 2: both in one launch — the shadow rays of level k and the nearest-hit rays of level k+1 do
 //         not depend on each other, and one launch has one drain instead of two.  A lane's kind is
 //         the sign of `bit` (>= 0: shadow ray of that light).
-template <int MODE, bool PRIMARY, bool COUNT>
+template <int MODE, bool PRIMARY, int COUNTING>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? WF_WAVES_EU_MIXED : WF_WAVES_EU, MODE == 2 ? WF_WAVES_EU_MIXED : WF_WAVES_EU)))
 void k_trace(TraceArgs A)
 {
+    // COUNTING 1: every statistic (tests, lane occupancy, coherence tables) and the units' costs; 2: the units' costs only
+    // (the pass that makes a claim order: as fast as a plain launch); 0: neither.
+    constexpr bool COUNT = COUNTING == 1, COST = COUNTING != 0;
     constexpr bool ANYHIT = MODE == 1;
     __shared__ int s_stack[WF_LDS_STACK * BLOCK];
     const int lane = threadIdx.x & 63;
@@ -140,7 +143,7 @@ void k_trace(TraceArgs A)
     Tally tl = { 0u, 0u, 0u };
     unsigned int dbg[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };   // COUNT: node iters/lanes, leaf iters/lanes, refills/lanes, idle / leaf-waiting lanes at node steps
     unsigned int box_slots = 0, nsteps = 0;                     // COUNT: box tests on occupied child slots; node steps of this lane's ray
-    unsigned int cur_unit = 0, my_unit = 0, ray_steps = 0;      // COUNT: the unit being dealt out; this lane's ray's unit and steps so far
+    unsigned int cur_unit = 0, my_unit = 0, ray_steps = 0;      // COST: the unit being dealt out; this lane's ray's unit and steps so far
     __shared__ unsigned long long s_coh[COUNT ? 3 * 16 * 4 : 1];
     if (COUNT) {
         for (int k = threadIdx.x; k < 3 * 16 * 4; k += BLOCK) s_coh[k] = 0ull;
@@ -195,7 +198,7 @@ void k_trace(TraceArgs A)
             break;
         }
 #endif
-        if (COUNT && A.cost && node == NODE_SENTINEL && ray_steps != 0u) {
+        if (COST && A.cost && node == NODE_SENTINEL && ray_steps != 0u) {
             // a ray has ended since the last look: its unit remembers its longest ray
             atomicMax(&A.cost[RTG(my_unit, n_units)], ray_steps);
             ray_steps = 0u;
@@ -220,7 +223,7 @@ void k_trace(TraceArgs A)
                 }
                 unsigned int u = (unsigned)unit;
                 if (A.order) u = (unsigned)RTG(A.order[u], n_units);     // the claim order of the launch: units with long rays first
-                if (COUNT) cur_unit = u;
+                if (COST) cur_unit = u;
                 const unsigned int per_seg = (unsigned)A.n_regions * UPR;
                 seg = (int)(u / per_seg);
 #if WF_CLOSEST_FIRST
@@ -286,7 +289,8 @@ void k_trace(TraceArgs A)
 #if WF_SETASIDE
                     stash = 0;
 #endif
-                    if (COUNT) { nsteps = 0; my_unit = cur_unit; ray_steps = 1u; }
+                    if (COUNT) nsteps = 0;
+                    if (COST) { my_unit = cur_unit; ray_steps = 1u; }
                 }
             }
             cur = min(end, cur + (unsigned)__popcll(idle));
@@ -335,9 +339,9 @@ void k_trace(TraceArgs A)
                     if (oct == first_oct) atomicAdd(c + 3, 1ull);
                 }
             }
-            if (at) { nsteps++; ray_steps++; }
+            if (at) nsteps++;
         }
-        if (COUNT && do_leaf && node < 0) ray_steps++;
+        if (COST && ((do_node && (unsigned)node < SENT_U) || (do_leaf && node < 0))) ray_steps++;
         if (do_node) {
             // ---- inner-node step: four children per 64-byte node
             if ((unsigned)node < SENT_U) {
@@ -555,9 +559,10 @@ typedef const __attribute__((address_space(4))) PkF4 *ConstF4P;
 #ifndef PK_WAVES
 #define PK_WAVES 8
 #endif
-template <bool COUNT>
+template <int COUNTING>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES))) void k_trace_packet(TraceArgs A)
 {
+    constexpr bool COUNT = COUNTING == 1, COST = COUNTING != 0;      // as in k_trace
     static_assert(UNIT <= 64, "a packet is one wave");
     const int lane = threadIdx.x & 63;
     const DevScene &sc = A.sc;
@@ -652,7 +657,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PK_WAVES,
                     if (m != 0ull) key[c] = (unsigned)__builtin_amdgcn_readlane(__float_as_int(tn[c]), __ffsll((long long)m) - 1);
                     if (COUNT) box_slots += (live && ref[c] != NODE_SENTINEL) ? 1u : 0u;
                 }
-                if (COUNT) { tl.box += live ? 4u : 0u; n_node_steps++; n_node_lanes += (unsigned)__popcll(alive); packet_steps++; }
+                if (COUNT) { tl.box += live ? 4u : 0u; n_node_steps++; n_node_lanes += (unsigned)__popcll(alive); }
+                if (COST) packet_steps++;
                 // children by the first entering lane's entry distance (non-negative floats order like their bits); all scalar
 #define PK_CSWAP(a, b)                                                          \
                 if (key[b] < key[a]) {                                          \
@@ -691,14 +697,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PK_WAVES,
                     }
                     if (COUNT && live) tl.tri += 1;
                 }
-                if (COUNT) { n_leaf_steps++; n_leaf_lanes += (unsigned)__popcll(alive); packet_steps++; }
+                if (COUNT) { n_leaf_steps++; n_leaf_lanes += (unsigned)__popcll(alive); }
+                if (COST) packet_steps++;
                 if (sp == 0) break;
                 sp--;
                 node = __builtin_amdgcn_readlane(stackv, sp);
             }
         }
         if (live) A.hits[RTG((unsigned)pr.pixel, A.n_pix)] = make_float2(best_t, __int_as_float(best_id));
-        if (COUNT && A.cost && lane == 0) A.cost[RTG(u, n_units)] = packet_steps;
+        if (COST && A.cost && lane == 0) A.cost[RTG(u, n_units)] = packet_steps;
     }
     if (COUNT) {
         unsigned int vals[4] = { tl.box, tl.tri, tl.analytic, box_slots };
@@ -909,10 +916,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 template <int MODE, bool PRIMARY>
-void launch_trace(const TraceArgs &a, bool count, int grid, hipStream_t stream)
+void launch_trace(const TraceArgs &a, int counting, int grid, hipStream_t stream)
 {
-    if (count) hipLaunchKernelGGL((k_trace<MODE, PRIMARY, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((k_trace<MODE, PRIMARY, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    if (counting == 1) hipLaunchKernelGGL((k_trace<MODE, PRIMARY, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else if (counting == 2) hipLaunchKernelGGL((k_trace<MODE, PRIMARY, 2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_trace<MODE, PRIMARY, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
 }
 
 }  // namespace
@@ -954,7 +962,8 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     const int n_regions = (int)wavefront_regions(n_slots);
     const int n_chunks = (scene.n_lights + 31) / 32;
     const int trace_grid = wavefront_trace_grid(num_cus);
-    const bool count = fp.count_tests != 0;
+    const bool count = fp.count_tests == 1;                              // every statistic
+    const int counting = fp.count_tests == 2 ? 2 : (count ? 1 : 0);      // 2: the claim units' costs only (FrameParams::count_tests)
     if (3 * fp.wide_depth + 1 > WF_LDS_STACK + WF_OVF) {
         if (err) *err = "LBVH deeper than the traversal stack";
         return RT_E_LIMIT;
@@ -1037,7 +1046,7 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
     auto launch_traversal = [&](int mode, int level, int chunk) -> int {
         t.cursors = cursor; cursor += SHARDS * CURSOR_STRIDE;
         const bool units_ok = ws.unit_cost && launch_index < ws.unit_launches;
-        t.cost = (fp.track_units && count && units_ok) ? ws.unit_cost + (size_t)launch_index * ws.unit_stride : nullptr;
+        t.cost = (fp.track_units && counting && units_ok) ? ws.unit_cost + (size_t)launch_index * ws.unit_stride : nullptr;
         t.order = (fp.use_order && units_ok) ? ws.unit_order + (size_t)launch_index * ws.unit_stride : nullptr;
         launch_index++;
         const int close_level = mode == 2 ? level + 1 : level;
@@ -1068,12 +1077,13 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         if (primary && packet) {
             // one wave per 8x8 tile: 8 waves per SIMD fit (few vector registers, no LDS)
             const int pgrid = num_cus * PK_WAVES;
-            if (count) hipLaunchKernelGGL(k_trace_packet<true>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
-            else hipLaunchKernelGGL(k_trace_packet<false>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
-        } else if (primary) launch_trace<0, true>(t, count, grid, stream);
-        else if (mode == 0) launch_trace<0, false>(t, count, grid, stream);
-        else if (mode == 1) launch_trace<1, false>(t, count, grid, stream);
-        else launch_trace<2, false>(t, count, grid, stream);
+            if (counting == 1) hipLaunchKernelGGL(k_trace_packet<1>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
+            else if (counting == 2) hipLaunchKernelGGL(k_trace_packet<2>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
+            else hipLaunchKernelGGL(k_trace_packet<0>, dim3(pgrid), dim3(BLOCK), 0, stream, t);
+        } else if (primary) launch_trace<0, true>(t, counting, grid, stream);
+        else if (mode == 0) launch_trace<0, false>(t, counting, grid, stream);
+        else if (mode == 1) launch_trace<1, false>(t, counting, grid, stream);
+        else launch_trace<2, false>(t, counting, grid, stream);
         launches++;
         return tstamp();
     };
@@ -1135,6 +1145,10 @@ int wavefront_frame(const DevScene &scene, const DevCamera &cam, const FramePara
         }
     }
     ws.trav_pairs = (int)(te / 2);
+    if (counting == 2) {        // a pass made for the units' costs: its picture is not wanted
+        *n_launches += launches;
+        return RT_OK;
+    }
     // ---- every level's local colour, the fold and the outputs, one thread per pixel
     if (int rc = shade_all_launch(scene, cam, fp, ws.p_hits, ws.p_occ, occ_chunks, ws.records, ws.counters, d_rgb8, d_hit_id,
                                   d_rgb32, d_hit_t, stream, num_cus, err))

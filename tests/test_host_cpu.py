@@ -340,14 +340,14 @@ def test_bench_reports_counter_traffic_only_for_the_sources_and_frame_it_was_mea
     (tmp_path / "profiles").mkdir()
     rec = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "bytes_per_frame": 123.0, "bytes_per_frame_as_counted": 77.0, "source": "x.txt"}}
     (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
-    valu = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "source": "x", "kernels": {"k_trace<2, false, false>": {"active_lanes": 40.0}}}}
+    valu = {"source_hash": source_hash(), "sponza": {"resolution": [1920, 1080], "source": "x", "kernels": {"k_trace<2, false, 0>": {"active_lanes": 40.0}}}}
     (tmp_path / "profiles" / "valu_counters.json").write_text(json.dumps(valu))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.measured_traffic("sponza", 1, (1920, 1080))[0] == (123.0, 77.0)     # FETCH_SIZE doubled, and as counted
     assert bench.measured_traffic("sponza", 1, (3840, 2160))[0] == (None, None)      # another frame size
     assert bench.measured_traffic("soup", 1, (1920, 1080))[0] == (None, None)        # another workload
     assert bench.measured_traffic("sponza", 2, (1920, 1080))[0] == (None, None)      # a partitioned run
-    assert bench.measured_valu("sponza", 1, (1920, 1080))[0]["k_trace<2, false, false>"]["active_lanes"] == 40.0
+    assert bench.measured_valu("sponza", 1, (1920, 1080))[0]["k_trace<2, false, 0>"]["active_lanes"] == 40.0
     assert bench.measured_valu("sponza", 1, (1280, 720))[0] is None
     rec["source_hash"] = "0" * 16
     (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(rec))
