@@ -360,3 +360,43 @@ def test_bench_reports_counter_traffic_only_for_the_sources_and_frame_it_was_mea
     # the committed file itself is either valid for the committed sources or reported as stale, never silently wrong
     committed = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     assert "source_hash" in committed and "sponza" in committed and committed["sponza"]["resolution"] == [1920, 1080]
+
+
+def test_counter_derivation_reads_the_newest_collection_and_only_the_plain_traversal_kernels(tmp_path, capsys):
+    """profiles/derive.py on a made-up collection directory: frames are the shading launches minus the full counting frames,
+    only the <.., 0> traversal kernels are summed, a camera-ray kernel that ran a handful of times (the timing runs of the
+    kernel choice) is left out, and of two collections merged into one directory only the newer counts."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("derive", os.path.join(ROOT, "profiles", "derive.py"))
+    derive = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(derive)
+    d = tmp_path / "prof"
+    (d / "trace" / "vm").mkdir(parents=True)
+    (d / "pmc1" / "vm").mkdir(parents=True)
+    ns = "void (anonymous namespace)::"
+
+    def stats(path, scale):
+        rows = [(ns + "k_trace<2, false, 0>(TraceArgs)", 40, 400000 * scale), (ns + "k_trace<2, false, 1>(TraceArgs)", 4, 1300000),
+                (ns + "k_trace<1, false, 0>(TraceArgs)", 10, 200000 * scale), (ns + "k_trace_packet<0>(TraceArgs)", 12, 150000 * scale),
+                (ns + "k_trace_packet<1>(TraceArgs)", 1, 500000), (ns + "k_trace<0, true, 0>(TraceArgs)", 3, 200000),
+                (ns + "k_trace<2, false, 2>(TraceArgs)", 4, 480000), (ns + "k_shade_all<5>(ShadeAllArgs)", 11, 125000)]
+        with open(path, "w") as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n')
+            for name, calls, avg in rows:
+                f.write('"%s",%d,%d,%d,1.0\n' % (name, calls, calls * avg, avg))
+
+    stats(d / "trace" / "vm" / "1_kernel_stats.csv", 7)          # an older collection in the same directory
+    time.sleep(0.02)
+    stats(d / "trace" / "vm" / "2_kernel_stats.csv", 1)
+    os.utime(d / "trace" / "vm" / "1_kernel_stats.csv", (1, 1))
+    with open(d / "pmc1" / "vm" / "9_counter_collection.csv", "w") as f:
+        f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+        for i in range(40):
+            f.write('%d,"%sk_trace<2, false, 0>(TraceArgs)","SQ_INSTS_VALU",%d\n' % (i + 1, ns, 200000000))
+    derive.main([str(d), "sponza", "1920", "1080"])
+    out = capsys.readouterr().out
+    assert "frames with plain kernels in the trace pass: 10 (of 11 frames)" in out
+    assert "traversal per frame: 1.950 ms" in out          # 4 x 400 + 200 + 150 us: the newer file, plain kernels only
+    assert "k_trace<0, true, 0>" in out and "timing runs" in out
+    assert "k_trace<2, false, 1>" not in out and "k_trace<2, false, 2>" not in out
