@@ -258,7 +258,7 @@ def test_camera_rays_as_packets_equal_the_per_lane_kernel(monkeypatch):
                 assert all(np.array_equal(x, y) for x, y in zip(f[:4], ref[:4])) and f[4] == ref[4], (mode, W, H)
 
 
-@pytest.mark.parametrize("seed", list(range(32)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_FUZZ_SEEDS", "32")))))
 def test_random_scenes_through_every_staged_kernel_choice_equal_the_oracle(seed, monkeypatch):
     """Seeded random frames: triangle count, leaf size, depth, frame size (any width and height, not tile multiples), a
     camera anywhere in or around the mesh with its window anywhere (so rays leave through every octant and some run
@@ -326,7 +326,7 @@ def test_random_scenes_through_every_staged_kernel_choice_equal_the_oracle(seed,
     monkeypatch.delenv("RT_WF_PACKET")
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_FUZZ_SEEDS", "32")) // 2)))
 def test_random_frames_through_the_other_entry_points_equal_the_staged_frame(seed):
     """The same kind of seeded random frame through the ways a frame can be asked for besides the staged whole-frame call:
     the fused kernel (RT_OPT_PIPELINE = 1), the linear scan, the entry point that allocates nothing, a random band
