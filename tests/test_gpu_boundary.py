@@ -422,3 +422,70 @@ def test_random_frames_through_the_other_entry_points_equal_the_staged_frame(see
                 assert (got[2] - ref[2]).abs().max().item() <= 4e-6, (seed, what)
             else:
                 same(got, ref, what)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_FUZZ_SEEDS", "32")) // 2)))
+def test_random_scenes_with_random_spheres_planes_lights_and_builders_equal_the_oracle(seed):
+    """Seeded random SCENES rather than random views of one kind of scene: zero to four spheres (some mirrors, some that
+    contain the camera), zero to two planes at any angle, 1 .. 40 lights (so the 32-light chunks of the occlusion words and
+    shadow queues are crossed), a triangle soup of 0 .. 1500 triangles with four materials, any of the three hierarchy
+    builders, leaf size, reference cutting on or off, depth 0 .. 4, both camera-ray kernels left to the library's choice.
+    The oracle's brute-force scan is the reference: ids and ray counts identical, colours within the parity bar, on the
+    first frame of the layout and on the ordered one."""
+    import torch
+    from common import SceneSpec, soup_spec, sphere, plane
+
+    g = np.random.default_rng(9000 + seed)
+    r = g.random(16)
+    n_lights = (1, 2, 3, 5, 31, 32, 33, 40)[int(r[0] * 8)]
+    n_tris = int(r[1] ** 2 * 1500) if n_lights <= 5 else int(r[1] ** 2 * 300)       # (the oracle tests every light against every triangle)
+    W, H = int(4 + r[2] * 90), int(4 + r[3] * 66)
+    D = int(r[4] * 5)
+    analytic = []
+    for k in range(n_lights):
+        p = g.random(3)
+        analytic.append(sphere((float(p[0] * 12 - 6), float(p[1] * 6 + 1), float(p[2] * 12 - 4)), 0.1,
+                               (0.0, 1.0, 1.0, tuple(float(c) for c in 0.3 + 0.7 * g.random(3) / max(1, n_lights // 2))), True))
+    for k in range(int(r[5] * 5)):
+        p = g.random(6)
+        mirror = p[4] < 0.4
+        analytic.append(sphere((float(p[0] * 8 - 4), float(p[1] * 6 - 3), float(p[2] * 8 - 1)), float(0.2 + p[3] ** 3 * 8),
+                               (1.0 if mirror else float(p[5] * 0.5), 0.0 if mirror else 1.0, 1.0, (0.9, 0.8, 0.7))))
+    for k in range(int(r[6] * 3)):
+        p = g.random(5)
+        n = np.array([p[0] - 0.5, p[1] + 0.2, p[2] - 0.5])
+        n = n / np.linalg.norm(n)
+        analytic.append(plane(tuple(float(c) for c in n), float(-2 - p[3] * 4), (float(p[4] * 0.6), 1.0, 1.0, (0.8, 0.8, 0.8))))
+    order = g.permutation(len(analytic))               # ids follow the array order: lights anywhere in it
+    analytic = [analytic[k] for k in order]
+    base = soup_spec(n_tris=max(n_tris, 1), seed=29 * seed + 11)
+    spec = SceneSpec(analytic, base.verts if n_tris else None, base.indices if n_tris else None, mats=base.mats if n_tris else None,
+                     tri_material=base.tri_material if n_tris else None)
+    origin = (float(r[7] * 6 - 3), float(r[8] * 4 - 2), float(r[9] * 6 - 6))
+    pitch = (3.0 + r[10] * 8.0) / max(W, H)
+    cam = rt.Camera(origin=origin, pitch=pitch, off_x=origin[0] - pitch * W * 0.5 + 0.013, off_y=origin[1] - pitch * H * 0.5 + 0.007,
+                    plane_z=origin[2] + 1.0)
+    want = to_oracle(spec).render(W, H, max_depth=D, cam=ocam(cam), threads=16)
+    builder = (rt.BUILDER_SAH, rt.BUILDER_PLOC, rt.BUILDER_LBVH)[int(r[11] * 3)]
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+        ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_WAVEFRONT if r[12] < 0.8 else rt.PIPELINE_FUSED)
+        ctx.set_option(rt.OPT_BUILDER, builder)
+        ctx.set_option(rt.OPT_LEAF_MAX, (1, 2, 4, 8)[int(r[13] * 4)])
+        ctx.set_option(rt.OPT_SPLIT, 1 if r[14] < 0.3 else 0)
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        first = None
+        for k in range(3):
+            f = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            assert (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]) == (
+                want["counts"]["primary"], want["counts"]["shadow"], want["counts"]["reflect"]), (seed, k)
+            if first is None:
+                first = f
+                c = compare(f, want)
+                assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0 and c["rgb8_exact"] >= 0.999 * c["pixels"] and c["rgb32_max_abs"] <= 4e-6, (seed, c)
+            else:
+                for key in ("rgb8", "hit_id", "rgb32"):
+                    assert np.array_equal(f[key].view(np.uint8), first[key].view(np.uint8)), (seed, k, key)
+        assert st["accel"] == (1 if n_tris >= 2 else 0)
