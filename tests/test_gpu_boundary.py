@@ -489,3 +489,43 @@ def test_random_scenes_with_random_spheres_planes_lights_and_builders_equal_the_
                 for key in ("rgb8", "hit_id", "rgb32"):
                     assert np.array_equal(f[key].view(np.uint8), first[key].view(np.uint8)), (seed, k, key)
         assert st["accel"] == (1 if n_tris >= 2 else 0)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_FUZZ_SEEDS", "32")) // 4)))
+def test_random_vertex_updates_keep_the_tree_and_equal_the_oracle(seed):
+    """A seeded random mesh is moved three times (rt_update_mesh_vertices: small jitter, a jitter as large as the mesh, a
+    collapse of every vertex towards one point) while frames of the same layout keep coming (so the claim order and the
+    camera-ray kernel chosen before the moves stay in use, stale): the refitted tree's frame equals the oracle's
+    brute-force scan over the moved mesh each time - ids and ray counts identical, colours within the parity bar."""
+    from common import SceneSpec, soup_spec
+
+    g = np.random.default_rng(12000 + seed)
+    r = g.random(8)
+    spec = soup_spec(n_tris=int(2 + r[0] ** 2 * 1500), seed=41 * seed + 1)
+    W, H, D = int(8 + r[1] * 100), int(8 + r[2] * 70), int(r[3] * 4)
+    cam = rt.Camera(pitch=8.0 / max(W, H) * (0.5 + r[4]))
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+        ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_WAVEFRONT)
+        ctx.set_option(rt.OPT_BUILDER, (rt.BUILDER_SAH, rt.BUILDER_PLOC, rt.BUILDER_LBVH)[int(r[5] * 3)])
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        for _ in range(3):                     # plain frame, order-making frame, ordered frame
+            ctx.render_frame(W, H, max_depth=D)
+        nodes0 = ctx.stats()["bvh_nodes"]
+        verts = spec.verts.astype(np.float32)
+        for step, scale in enumerate((0.02, 3.0, None)):
+            if scale is None:
+                verts = (verts * 0.05 + np.array([0.3, -1.0, 2.0], np.float32)).astype(np.float32)
+            else:
+                verts = (verts + (g.random(verts.shape) - 0.5) * scale).astype(np.float32)
+            ctx.update_mesh_vertices(verts)
+            got = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            assert st["accel"] == 1 and st["bvh_nodes"] == nodes0
+            moved = SceneSpec(spec.analytic, verts, spec.indices, spec.mesh_mat, spec.mats, spec.tri_material)
+            want = to_oracle(moved).render(W, H, max_depth=D, cam=ocam(cam), threads=16)
+            c = compare(got, want)
+            assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0 and c["rgb32_max_abs"] <= 4e-6, (seed, step, c)
+            assert (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]) == (
+                want["counts"]["primary"], want["counts"]["shadow"], want["counts"]["reflect"]), (seed, step)
