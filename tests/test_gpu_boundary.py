@@ -529,3 +529,34 @@ def test_random_vertex_updates_keep_the_tree_and_equal_the_oracle(seed):
             assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0 and c["rgb32_max_abs"] <= 4e-6, (seed, step, c)
             assert (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]) == (
                 want["counts"]["primary"], want["counts"]["shadow"], want["counts"]["reflect"]), (seed, step)
+
+
+@pytest.mark.parametrize("seed", list(range(max(4, int(os.environ.get("RT_FUZZ_SEEDS", "32")) // 8))))
+def test_random_mid_size_frames_equal_the_oracles_own_hierarchy(seed):
+    """Frames large enough for many queue regions, thousands of packet tiles and deep trees (300..1000 pixels wide,
+    5 000..125 000 small random triangles, depth 1..4), against the oracle with ITS hierarchy (an independent median-split
+    BVH; the brute-force scan would take minutes): ids and ray counts identical, colours within the parity bar, on the
+    plain frame, the order-making frame and the ordered frame."""
+    from common import soup_spec
+
+    r = np.random.default_rng(500 + seed).random(8)
+    n_tris = int(5000 + r[0] * 120000)
+    W, H, D = int(300 + r[1] * 700), int(200 + r[2] * 500), int(1 + r[3] * 4)
+    spec = soup_spec(n_tris=n_tris, seed=seed + 77)
+    tri = spec.verts.reshape(-1, 3, 3)
+    centre = tri.mean(1, keepdims=True)
+    spec.verts = ((tri - centre) * (0.05 + 0.3 * r[4]) + centre).reshape(-1, 3).astype(np.float32)   # small triangles: rays go deep
+    cam = rt.Camera(origin=(float(r[5] * 2 - 1), float(r[6] * 2 - 1), -6.0), pitch=8.0 / W)
+    want = to_oracle(spec, bvh=True).render(W, H, max_depth=D, cam=ocam(cam), use_bvh=True, threads=16)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.OPT_LEAF_MAX, (1, 2, 4)[seed % 3])
+        to_product(ctx, spec)
+        ctx.set_camera(cam)
+        for k in range(3):
+            f = ctx.render_frame(W, H, max_depth=D)
+            st = ctx.stats()
+            c = compare(f, want)
+            assert c["id_mismatch"] == 0 and c["rgb8_over_tol"] == 0 and c["rgb32_max_abs"] <= 4e-6, (seed, k, c)
+            assert (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]) == (
+                want["counts"]["primary"], want["counts"]["shadow"], want["counts"]["reflect"]), (seed, k)
+        assert st["accel"] == 1
