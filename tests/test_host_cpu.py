@@ -400,3 +400,22 @@ def test_counter_derivation_reads_the_newest_collection_and_only_the_plain_trave
     assert "traversal per frame: 1.950 ms" in out          # 4 x 400 + 200 + 150 us: the newer file, plain kernels only
     assert "k_trace<0, true, 0>" in out and "timing runs" in out
     assert "k_trace<2, false, 1>" not in out and "k_trace<2, false, 2>" not in out
+
+
+def test_obj_loader_survives_made_up_files_under_the_sanitizers(tmp_path):
+    """tests/objfuzz.cpp: 3000 made-up OBJ files (with a made-up .mtl beside some of them) through both tokenizers of the
+    host's loader, compiled with -fsanitize=address,undefined: no crash, no report, and no index handed out that points
+    outside what was loaded.  (The reference's parser asserts or reads out of bounds on such input, objloader.cpp:83.)"""
+    exe = str(tmp_path / "objfuzz")
+    host = os.path.join(ROOT, "raytracer_amd", "host")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "objfuzz.cpp"),
+                        os.path.join(host, "objhost_c.cpp"), os.path.join(host, "objloader.cpp"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr.lower():
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ)
+    env["ASAN_OPTIONS"] = "verify_asan_link_order=0"      # (another preloaded library may come before the sanitizer's runtime)
+    r = subprocess.run([exe, str(tmp_path), "3000"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    assert "no crash, no index out of range" in r.stdout
