@@ -153,7 +153,8 @@ int rt_set_analytic(rt_ctx *ctx, const rt_analytic *prims, int n);
 /* Replaces LoadModel(const char*), main.cpp:219-232: every index triple becomes a
  * Triangle (constructor main.cpp:104-107 runs on the device), appended after the
  * analytic primitives (ids n_analytic + k).  `mat` NULL = reference default material.
- * Builds the LBVH on the device.  verts = n_verts x (x,y,z). */
+ * Builds the LBVH on the device.  verts = n_verts x (x,y,z).  The call replaces the mesh: when it fails (an index
+ * outside the vertices -> RT_E_INVALID, where the reference reads out of bounds) the context holds no mesh at all. */
 int rt_set_mesh(rt_ctx *ctx, const float *verts, int n_verts, const int32_t *indices, int n_indices,
                 const rt_material *mat);
 

@@ -16,6 +16,7 @@ LIB = os.path.join(HERE, "librt_amd.so")
 HOST_BIN = os.path.join(HERE, "bin", "raytracer")
 OBJHOST_LIB = os.path.join(HERE, "libobjhost.so")
 GUARD_LIB = os.path.join(HERE, "variants", "guard.so")
+SHIM_ASAN = os.path.join(HERE, "variants", "shim_asan")
 
 HIP_SOURCES = ["rt_shim.hip", "trace.hip", "wavefront.hip", "shade.hip", "lbvh.hip"]
 HIP_FLAGS = [
@@ -82,6 +83,25 @@ def build_guard(force=False, verbose=False):
     return build_lib(force=force, verbose=verbose, extra_flags=("-DRT_GUARD=1",), out=GUARD_LIB)
 
 
+def build_shim_asan(force=False, verbose=False):
+    """variants/shim_asan: tests/shim_asan_driver.cpp linked with the library's own sources, the HOST side compiled with the
+    address and undefined-behaviour sanitizers (device code as always).  A GPU test runs it: the shim's buffer, vector and
+    thread handling under the sanitizers, through the C ABI."""
+    out = SHIM_ASAN
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES] + [os.path.join(ROOT, "tests", "shim_asan_driver.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "rt_shim.h")]
+    if not force and _newer(out, deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    flags = [f for f in HIP_FLAGS if f not in ("-fPIC", "-shared", "-O3")]
+    cmd = [_hipcc()] + flags + ["-O2", "-g", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+                                "-Xarch_host", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + srcs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_objhost(force=False, verbose=False):
     """libobjhost.so: include/rt_objhost.h, the host's OBJ loader behind a C ABI (no GPU code)."""
     srcs = [os.path.join(HOST, "objhost_c.cpp"), os.path.join(HOST, "objloader.cpp")]
@@ -118,6 +138,7 @@ def build_host(force=False, verbose=False):
 def build_all(force=False, verbose=False):
     build_lib(force=force, verbose=verbose)
     build_guard(force=force, verbose=verbose)
+    build_shim_asan(force=force, verbose=verbose)
     build_host(force=force, verbose=verbose)
     build_objhost(force=force, verbose=verbose)
 

@@ -560,3 +560,22 @@ def test_random_mid_size_frames_equal_the_oracles_own_hierarchy(seed):
             assert (st["rays_primary"], st["rays_shadow"], st["rays_reflect"]) == (
                 want["counts"]["primary"], want["counts"]["shadow"], want["counts"]["reflect"]), (seed, k)
         assert st["accel"] == 1
+
+
+def test_the_shims_host_code_under_the_address_and_undefined_behaviour_sanitizers():
+    """raytracer_amd/variants/shim_asan (raytracer_amd.build.build_shim_asan: tests/shim_asan_driver.cpp linked with the
+    library's sources, host side sanitized): the C ABI's host paths - the hand-over into pageable and library buffers with
+    its helper threads, row ranges, all planes, the claim order's counting sort, frame slots with a rebuild while frames
+    are pending, band reassembly, the no-alloc entry point, statistics for an older header, vertex updates, refused
+    calls, a second context - produce the expected bytes and no sanitizer report."""
+    from raytracer_amd import build
+    if not os.path.exists(build.SHIM_ASAN):
+        pytest.skip("variants/shim_asan is not built (raytracer_amd.build.build_shim_asan)")
+    env = dict(os.environ)
+    # leaks at exit belong to the HIP runtime; another preloaded library may come before the sanitizer's runtime; the GPU
+    # driver maps memory where the sanitizer keeps its shadow gap
+    env["ASAN_OPTIONS"] = "detect_leaks=0:verify_asan_link_order=0:protect_shadow_gap=0"
+    env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    r = subprocess.run([build.SHIM_ASAN], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "shim driver ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
