@@ -123,7 +123,7 @@ def test_guarded_build_reports_a_traversal_stack_that_dropped_a_child():
     assert "ERROR" in out and "guarded build" in out and "NO ERROR" not in out
 
 
-HOST_BIN = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+HOST_BIN = os.environ.get("RT_HOST_BIN") or os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")      # (RT_HOST_BIN: another build of the host, e.g. a sanitized one)
 
 
 def _ppm(path):

@@ -676,7 +676,7 @@ def test_per_triangle_materials_and_material_update():
 
 
 # ------------------------------------------------------------------ the C++ host
-HOST_BIN = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+HOST_BIN = os.environ.get("RT_HOST_BIN") or os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")      # (RT_HOST_BIN: another build of the host, e.g. a sanitized one)
 
 
 def _read_ppm(path):

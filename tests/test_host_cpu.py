@@ -13,7 +13,7 @@ import pytest
 
 from common import GOLDEN, ROOT, rt, scenes
 
-HOST_BIN = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+HOST_BIN = os.environ.get("RT_HOST_BIN") or os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")      # (RT_HOST_BIN: another build of the host, e.g. a sanitized one)
 
 
 def test_library_exports_every_declared_symbol():
