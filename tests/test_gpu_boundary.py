@@ -579,3 +579,40 @@ def test_the_shims_host_code_under_the_address_and_undefined_behaviour_sanitizer
     r = subprocess.run([build.SHIM_ASAN], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "shim driver ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_contexts_give_their_device_memory_back():
+    """Twenty-five contexts made, used in every allocating way (scene, hierarchy, staged and fused workspaces, four frame
+    slots with captured graphs, pinned staging, a library host buffer the caller forgets to free, a refit) and destroyed:
+    the device's free memory after the last is what it was after the fifth."""
+    import torch
+    torch.zeros(1, device="cuda")
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    spec = atrium_spec(detail=0.05)
+    W, H = 640, 400
+    baseline = None
+    for it in range(25):
+        with rt.Context(0) as ctx:
+            to_product(ctx, spec)
+            ctx.set_camera(rt.Camera(origin=(0.0, -1.5, -6.0), pitch=8.0 / W, off_x=-4.0, off_y=-3.4))
+            for _ in range(3):
+                ctx.render_frame(W, H, max_depth=3)
+            buf = ctx.alloc_host_buffer((H, W, 3))          # not freed: the context releases it
+            ctx.render_frame_into(W, H, buf, max_depth=3)
+            t = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+            for slot in range(4):
+                for _ in range(3):
+                    ctx.render_rows_device(W, H, rt.RowSet(0, 1, 1, H), 3, d_rgb8=t.data_ptr(), slot=slot)
+            ctx.synchronize()
+            ctx.set_option(rt.OPT_PIPELINE, rt.PIPELINE_FUSED)
+            ctx.render_frame(W // 2, H // 2, max_depth=2)
+            ctx.update_mesh_vertices(spec.verts * 1.01)
+            ctx.render_frame(W // 2, H // 2, max_depth=2)
+            del t
+        if it == 4:
+            baseline = free_bytes()
+    assert baseline - free_bytes() < (8 << 20), (baseline, free_bytes())
