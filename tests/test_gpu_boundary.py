@@ -616,3 +616,50 @@ def test_contexts_give_their_device_memory_back():
         if it == 4:
             baseline = free_bytes()
     assert baseline - free_bytes() < (8 << 20), (baseline, free_bytes())
+
+
+def test_contexts_on_four_host_threads_at_once():
+    """One host thread per context is the rule; contexts themselves are independent: four threads, each with a context of
+    its own and a scene of its own, render frames at the same time (host-buffer frames, device frames, a rebuild, the
+    claim order's calibration somewhere in between).  Every thread's frames equal what the same calls give alone."""
+    import threading
+    from common import soup_spec
+
+    specs = [atrium_spec(detail=0.05), soup_spec(n_tris=900, seed=3), cube_spec(mirror=False, mesh_reflect=0.5), soup_spec(n_tris=5000, seed=8)]
+    sizes = [(320, 200, 3), (257, 131, 2), (400, 300, 4), (199, 240, 1)]
+
+    def work(k, out, rounds):
+        try:
+            W, H, D = sizes[k]
+            with rt.Context(0) as ctx:
+                ctx.set_option(rt.OPT_ACCEL, rt.ACCEL_LBVH)
+                to_product(ctx, specs[k])
+                ctx.set_camera(rt.Camera(pitch=8.0 / W))
+                frames = []
+                for r in range(rounds):
+                    if r == rounds // 2:
+                        ctx.set_option(rt.OPT_LEAF_MAX, 4)          # a rebuild in the middle
+                    f = ctx.render_frame(W, H, max_depth=D)
+                    st = ctx.stats()
+                    frames.append((f["rgb8"].copy(), f["hit_id"].copy(), f["rgb32"].view(np.uint32).copy(),
+                                   (st["rays_primary"], st["rays_shadow"], st["rays_reflect"])))
+                out[k] = frames
+        except Exception as e:          # (reported by the main thread)
+            out[k] = e
+
+    alone = {}
+    for k in range(4):
+        work(k, alone, 2)
+        assert not isinstance(alone[k], Exception), alone[k]
+    together = {}
+    threads = [threading.Thread(target=work, args=(k, together, 12)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive()
+    for k in range(4):
+        assert not isinstance(together[k], Exception), together[k]
+        ref = alone[k][0]
+        for n, f in enumerate(together[k]):
+            assert all(np.array_equal(a, b) for a, b in zip(f[:3], ref[:3])) and f[3] == ref[3], (k, n)
