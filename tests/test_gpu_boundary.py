@@ -577,6 +577,8 @@ def test_the_shims_host_code_under_the_address_and_undefined_behaviour_sanitizer
     env["ASAN_OPTIONS"] = "detect_leaks=0:verify_asan_link_order=0:protect_shadow_gap=0"
     env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
     r = subprocess.run([build.SHIM_ASAN], capture_output=True, text=True, timeout=300, env=env)
+    if r.returncode != 0 and any(w in r.stderr for w in ("ReserveShadowMemoryRange", "Shadow memory range interleaves", "failed to mmap")):
+        pytest.skip("the sanitizer's runtime could not set itself up in this process image: " + r.stderr[-300:])
     assert r.returncode == 0 and "shim driver ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
