@@ -721,6 +721,17 @@ int hand_over(rt_ctx *c, const HostPlane *planes, int n_planes)
 
 }  // namespace
 
+// No C++ exception leaves the library: a caller of a C ABI cannot catch one.  Every entry point with a body that can throw
+// (std::vector, std::string, std::thread) is a function-try-block that turns the exception into an error code.  The texts are
+// short enough for the string's own buffer, so reporting "out of memory" allocates nothing.
+#define RT_ABI_CATCH_INT                                                                       \
+    catch (const std::bad_alloc &) { g_err = "out of memory"; return RT_E_NOMEM; }             \
+    catch (...) { g_err = "C++ exception"; return RT_E_DEVICE; }
+#define RT_ABI_CATCH_PTR                                                                       \
+    catch (const std::bad_alloc &) { g_err = "out of memory"; return nullptr; }                \
+    catch (...) { g_err = "C++ exception"; return nullptr; }
+#define RT_ABI_CATCH_VOID catch (...) { }
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -728,7 +739,7 @@ int rt_abi_version(void) { return RT_ABI_VERSION; }
 const char *rt_last_error(void) { return g_err.c_str(); }
 
 rt_ctx *rt_create(int device_ordinal)
-{
+try {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -770,10 +781,10 @@ rt_ctx *rt_create(int device_ordinal)
     }
     default_camera(&c->cam);
     return c;
-}
+} RT_ABI_CATCH_PTR
 
 void rt_destroy(rt_ctx *c)
-{
+try {
     if (!c) return;
     DeviceGuard g(c->device);
     quiesce(c);
@@ -791,10 +802,10 @@ void rt_destroy(rt_ctx *c)
         if (f.frame_done) (void)hipEventDestroy(f.frame_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
-}
+} RT_ABI_CATCH_VOID
 
 int rt_set_option(rt_ctx *c, int option, int value)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     switch (option) {
     case RT_OPT_ACCEL:
@@ -826,10 +837,10 @@ int rt_set_option(rt_ctx *c, int option, int value)
         return RT_OK;
     default: return fail(RT_E_INVALID, "unknown option");
     }
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_analytic(rt_ctx *c, const rt_analytic *prims, int n)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (n < 0 || (n > 0 && !prims)) return fail(RT_E_INVALID, "bad analytic array");
     if (n > RT_MAX_ANALYTIC) return fail(RT_E_LIMIT, "more than RT_MAX_ANALYTIC analytic primitives");
@@ -867,10 +878,10 @@ int rt_set_analytic(rt_ctx *c, const rt_analytic *prims, int n)
     c->n_analytic = n;
     c->n_lights = (int)lights.size();
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_triangles(rt_ctx *c, const float *tri_verts, int n_tris, const rt_material *mat)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (n_tris < 0 || (n_tris > 0 && !tri_verts)) return fail(RT_E_INVALID, "bad triangle array");
     if ((long long)n_tris * 8 >= (1ll << 31)) return fail(RT_E_LIMIT, "too many triangles");
@@ -896,10 +907,10 @@ int rt_set_triangles(rt_ctx *c, const float *tri_verts, int n_tris, const rt_mat
     (void)hipFree(d_v);
     if (rc != RT_OK) free_triangles(c);
     return rc;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indices, int n_indices, const rt_material *mat)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (n_verts < 0 || n_indices < 0 || (n_verts > 0 && !verts) || (n_indices > 0 && !indices))
         return fail(RT_E_INVALID, "bad mesh arrays");
@@ -947,7 +958,7 @@ int rt_set_mesh(rt_ctx *c, const float *verts, int n_verts, const int32_t *indic
         c->n_mesh_verts = n_verts;
     }
     return rc;
-}
+} RT_ABI_CATCH_INT
 
 namespace {
 
@@ -982,7 +993,7 @@ int after_vertex_update(rt_ctx *c)
 }  // namespace
 
 int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (!tri_verts) return fail(RT_E_INVALID, "null vertex array");
     if (c->n_tris == 0 || n_tris != c->n_tris) return fail(RT_E_STATE, "triangle count does not match the loaded triangles");
@@ -998,10 +1009,10 @@ int rt_update_triangles(rt_ctx *c, const float *tri_verts, int n_tris)
     if (rc == RT_OK) rc = after_vertex_update(c);
     (void)hipStreamSynchronize(c->stream);
     return rc;
-}
+} RT_ABI_CATCH_INT
 
 int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (!verts) return fail(RT_E_INVALID, "null vertex array");
     if (!c->d_indices || c->n_tris == 0) return fail(RT_E_STATE, "no indexed mesh loaded (rt_set_mesh)");
@@ -1023,10 +1034,10 @@ int rt_update_mesh_vertices(rt_ctx *c, const float *verts, int n_verts)
     if (rc == RT_OK) rc = after_vertex_update(c);
     (void)hipStreamSynchronize(c->stream);
     return rc;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_triangle_materials(rt_ctx *c, const rt_material *mats, int n_mats, const int32_t *tri_material, int n_tris)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (!mats || n_mats < 1 || !tri_material) return fail(RT_E_INVALID, "bad material arrays");
     if (n_tris != c->n_tris || c->n_tris == 0) return fail(RT_E_STATE, "triangle count does not match the loaded mesh");
@@ -1052,10 +1063,10 @@ int rt_set_triangle_materials(rt_ctx *c, const rt_material *mats, int n_mats, co
     c->d_mats = nm;
     c->n_mats = n_mats;
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_triangle_normals(rt_ctx *c, const float *corner_normals, int n_tris)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     quiesce(c);
@@ -1079,10 +1090,10 @@ int rt_set_triangle_normals(rt_ctx *c, const float *corner_normals, int n_tris)
     c->d_tri_vn = d;
     c->state_version++;
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_triangle_texcoords(rt_ctx *c, const float *corner_uv, int n_tris)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     quiesce(c);
@@ -1104,19 +1115,19 @@ int rt_set_triangle_texcoords(rt_ctx *c, const float *corner_uv, int n_tris)
     c->d_tri_vt = d;
     c->state_version++;
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_set_camera(rt_ctx *c, const rt_camera *cam)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (!cam) { default_camera(&c->cam); return RT_OK; }
     c->cam.ox = cam->origin[0]; c->cam.oy = cam->origin[1]; c->cam.oz = cam->origin[2];
     c->cam.pitch = cam->pitch; c->cam.off_x = cam->off_x; c->cam.off_y = cam->off_y; c->cam.plane_z = cam->plane_z;
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint8_t *rgb8, int32_t *hit_id, float *rgb32)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
     DeviceGuard g(c->device);
@@ -1129,10 +1140,10 @@ int rt_render_frame(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, uint
     const HostPlane planes[3] = { { rgb8, c->f->ws.out_rgb8, 3 * pixels }, { hit_id, c->f->ws.out_id, sizeof(int32_t) * pixels },
                                   { rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels } };
     return hand_over(c, planes, 3);
-}
+} RT_ABI_CATCH_INT
 
 int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_depth, const rt_frame_planes *out)
-{
+try {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(RT_E_INVALID, "bad row range");
     DeviceGuard g(c->device);
@@ -1146,10 +1157,10 @@ int rt_render_frame_planes(rt_ctx *c, int W, int H, int y0, int y1, int max_dept
                                   { out->rgb32, c->f->ws.out_rgb32, sizeof(float) * 3 * pixels }, { out->hit_t, c->f->ws.hit_t, sizeof(float) * pixels },
                                   { out->normal, c->f->ws.out_normal, sizeof(float) * 3 * pixels }, { out->uv, c->f->ws.out_uv, sizeof(float) * 2 * pixels } };
     return hand_over(c, planes, 6);
-}
+} RT_ABI_CATCH_INT
 
 void *rt_alloc_host_buffer(rt_ctx *c, uint64_t bytes)
-{
+try {
     if (!c || bytes == 0) { fail(RT_E_INVALID, "rt_alloc_host_buffer: null context or no bytes"); return nullptr; }
     DeviceGuard g(c->device);
     void *p = nullptr;
@@ -1160,10 +1171,10 @@ void *rt_alloc_host_buffer(rt_ctx *c, uint64_t bytes)
     }
     c->pinned.push_back({ (unsigned char *)p, (size_t)bytes });
     return p;
-}
+} RT_ABI_CATCH_PTR
 
 int rt_free_host_buffer(rt_ctx *c, void *buffer)
-{
+try {
     if (!c || !buffer) return fail(RT_E_INVALID, "rt_free_host_buffer: null argument");
     DeviceGuard g(c->device);
     for (size_t k = 0; k < c->pinned.size(); k++)
@@ -1174,29 +1185,29 @@ int rt_free_host_buffer(rt_ctx *c, void *buffer)
             return RT_OK;
         }
     return fail(RT_E_STATE, "rt_free_host_buffer: not a buffer of rt_alloc_host_buffer");
-}
+} RT_ABI_CATCH_INT
 
 int rt_render_rows_device(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
                           void *d_rgb32, void *d_hit_t, void *stream)
-{
+try {
     return rt_render_rows_device_slot(c, 0, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, stream);
-}
+} RT_ABI_CATCH_INT
 
 int rt_render_rows_device_slot(rt_ctx *c, int slot, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
                                void *d_rgb32, void *d_hit_t, void *stream)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return render_common(c, W, H, rows, max_depth, d_rgb8, d_hit_id, d_rgb32, d_hit_t, s, false, false, slot);
-}
+} RT_ABI_CATCH_INT
 
 // The frame of rt_render_rows_device through the one-kernel-per-bounce-level pipeline, with every intermediate
 // buffer (ray queues, per-level records, counters) carved out of this GPU's static scratch array: no hipMalloc,
 // no hipFree, no event or graph creation.  Calls that overlap on one GPU share the array and race.
 int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows, int max_depth, void *d_rgb8, void *d_hit_id,
                                   void *d_rgb32, void *d_hit_t, void *stream)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     if (int rc = validate_rows(W, H, rows)) return rc;
@@ -1281,11 +1292,11 @@ int rt_render_rows_device_noalloc(rt_ctx *c, int W, int H, const rt_rowset *rows
     c->f->last_wavefront = false;
     c->f->last_primary = pixels;
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_deinterleave_bands(rt_ctx *c, const void *d_src, void *d_dst, int W, int H, int band_rows, int n_parts,
                           int rows_per_part, int bytes_per_pixel, void *stream)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     if (!d_src || !d_dst || W <= 0 || H <= 0 || band_rows < 1 || n_parts < 1 || rows_per_part < 0)
         return fail(RT_E_INVALID, "bad de-interleave arguments");
@@ -1300,19 +1311,19 @@ int rt_deinterleave_bands(rt_ctx *c, const void *d_src, void *d_dst, int W, int 
     if (trace_deinterleave(d_src, d_dst, W, H, band_rows, n_parts, rows_per_part, bytes_per_pixel, s) != RT_OK)
         return fail(RT_E_DEVICE, "de-interleave launch failed");
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_synchronize(rt_ctx *c)
-{
+try {
     if (!c) return fail(RT_E_INVALID, "null context");
     DeviceGuard g(c->device);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(RT_E_DEVICE, hipGetErrorString(e));
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_get_stats_sized(rt_ctx *c, rt_stats *out, uint64_t size)
-{
+try {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
     if (size == 0 || size % 4 != 0) return fail(RT_E_INVALID, "rt_get_stats_sized: size must be a positive multiple of 4");
     rt_stats full;
@@ -1320,10 +1331,10 @@ int rt_get_stats_sized(rt_ctx *c, rt_stats *out, uint64_t size)
     if (rc != RT_OK) return rc;
     memcpy(out, &full, size < sizeof full ? (size_t)size : sizeof full);
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 int rt_get_stats(rt_ctx *c, rt_stats *out)
-{
+try {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
     DeviceGuard g(c->device);
     memset(out, 0, sizeof *out);
@@ -1402,6 +1413,6 @@ int rt_get_stats(rt_ctx *c, rt_stats *out)
         }
     }
     return RT_OK;
-}
+} RT_ABI_CATCH_INT
 
 }  // extern "C"
