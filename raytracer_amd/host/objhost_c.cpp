@@ -18,6 +18,7 @@ rt_obj *rt_obj_load(const char *path, int relaxed)
 {
     rt_obj *o = new (std::nothrow) rt_obj();
     if (!o) return nullptr;
+    try {                               // (the parser's vectors may run out of memory: NULL, never an exception through a C ABI)
     if (relaxed) {
         (void)LoadModelEx(path, o->m);
     } else {
@@ -29,6 +30,10 @@ rt_obj *rt_obj_load(const char *path, int relaxed)
         d.reflect = 0.0f; d.diffuse = 1.0f; d.spec = 1.0f;
         d.color[0] = d.color[1] = d.color[2] = 1.0f;
         o->m.materials.push_back(d);
+    }
+    } catch (...) {
+        delete o;
+        return nullptr;
     }
     return o;
 }
