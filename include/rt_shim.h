@@ -128,7 +128,7 @@ enum {
                                 records the longest ray of every 64-ray work unit (and by two short timing runs that pick the camera-ray
                                 kernel); every later frame of that layout hands the units out longest first.  The order decides when a
                                 ray is traced, never what it hits: frames are bit-identical with it on or off, and a moved camera or
-                                refitted mesh keeps using it (it goes stale gracefully).  That one frame costs about four frames and the
+                                refitted mesh keeps using it (its worth fades as the view moves: it records which units hold the longest rays).  That one frame costs about four frames and the
                                 call waits for it (one host synchronisation); a caller that renders a single frame never pays it.
                                 0: off.  2: drop the order; the next repeating layout makes a new one (then back to 1). */
 };
