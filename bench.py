@@ -420,6 +420,14 @@ def main():
             with torch.cuda.stream(pr.stream):
                 out["eager_ms_per_step"] = timed_frames(pr.render, sync_all, a.steps, 2)
             ctx.set_option(rt.OPT_GRAPH, 0 if a.no_graph else 1)
+            # the same frames with the work units handed out in plain order: what a frame takes without the claim order, which
+            # is a record of THIS view's longest rays (it is what a moving camera gets: the order's worth fades with the view)
+            ctx.set_option(rt.OPT_CLAIM_ORDER, 0)
+            with torch.cuda.stream(pr.stream):
+                t_plain = timed_frames(pr.render, sync_all, a.steps, 3)
+            ctx.set_option(rt.OPT_CLAIM_ORDER, 1)
+            out["plain_order"] = {"ms_per_step": t_plain, "value": rays / t_plain / 1e3, "unit": "Mrays/s",
+                                  "note": "RT_OPT_CLAIM_ORDER off: units claimed in screen order; not the headline"}
             out.update(host_frame_times(ctx, wl, min(a.steps, 10)))
             if st["accel"]:
                 out["share_ms"] = share_table(ctx, 1, wl, a.band_rows, torch, dev)
