@@ -398,6 +398,9 @@ def main():
                        "bvh_sah_cost": round(st["bvh_sah_cost"], 2), "bvh_refs": st["bvh_refs"],
                        "leaf_max": st["bvh_leaf_max"], "partition": "%d-row bands round-robin" % a.band_rows if world > 1 else "none",
                        "frames_in_flight": in_flight,
+                       # every step redraws one still frame, as the reference's loop does (main.cpp:284-287): the work units are
+                       # claimed in the order recorded for this view (RT_OPT_CLAIM_ORDER; `plain_order` is the rate without it)
+                       "view": "still", "claim_order": "recorded for this view",
                        "rays_per_frame": {"primary": rp, "shadow": rs, "reflect": rr}},
             "device_ms_per_frame": ms_frame, "lbvh_build_ms": st["ms_build"],
             "roofline": roofline,
