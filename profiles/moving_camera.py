@@ -1,9 +1,11 @@
-"""profiles/moving_camera.py: the bench workload with the camera moving every frame (no graph replay: every frame differs; the
+"""profiles/moving_camera.py [step ...]: the bench workload with the camera moving every frame (no graph replay: every frame differs; the
 claim order made for the first view goes stale as the camera moves on), ms per frame with the claim order on and off, and
 with a new order made every 50 frames."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("RT_AMD_LIB"):
+    pass        # (raytracer_amd loads the library this names: A/B of builds)
 import raytracer_amd as rt
 from raytracer_amd import workloads
 
@@ -34,6 +36,7 @@ def run(order, renew_every=0, frames=200, step=0.01):
         return (time.perf_counter() - t0) / frames * 1e3
 
 
-for step in (0.002, 0.01, 0.05):
-    print("camera step %.3f per frame over 200 frames: order off %.3f ms, order of the first view %.3f ms, new order every 50 frames %.3f ms (its making included)" % (
+steps = [float(x) for x in sys.argv[1:]] or [0.002, 0.01, 0.05]
+for step in steps:
+    print("camera step %g per frame over 200 frames: order off %.3f ms, order of the first view %.3f ms, new order every 50 frames %.3f ms (its making included)" % (
         step, run(0, step=step), run(1, step=step), run(1, 50, step=step)), flush=True)
